@@ -1,0 +1,176 @@
+"""Pins the CPU oracle (oracle/ref_cpu.py) to vectors produced by the real reference
+(oracle/make_golden.py).  The reference has no tests of its own, so these vectors are
+the parity anchor for everything else.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from ddim_audio_amd import configs, schedule, synth
+from oracle import ref_cpu
+from conftest import rel_err
+
+CPU = "torch.FloatTensor"
+TOL = 2e-5  # max-abs relative to output std; fp32-vs-fp64 noise of the reference itself is ~3e-6
+
+
+def _sd(shapes, seed=0):
+    sd = {k: torch.empty(s) for k, s in shapes.items()}
+    return synth.fill_state_dict(sd, seed)
+
+
+def _rb_shapes(p, c):
+    return {p + "norm.0.weight": (c,), p + "norm.0.bias": (c,), p + "norm.1.weight": (c,), p + "norm.1.bias": (c,),
+            p + "norm.2.weight": (c,), p + "conv.0.weight": (c, c, 3, 3), p + "conv.1.weight": (c, c, 3, 3),
+            p + "conv.1.bias": (c,)}
+
+
+def full_state(cfg, seed=0):
+    """State dict with the reference's 389 names/shapes, built from the product's own inventory."""
+    from ddim_audio_amd.model import state_inventory
+    inv = state_inventory(cfg)
+    sd = {k: torch.empty(s) for k, s in inv.items()}
+    synth.fill_state_dict(sd, seed)
+    sd["temb.te"] = ref_cpu.timestep_table(cfg.diffusion.num_diffusion_timesteps)
+    return sd
+
+
+def test_schedule_tables(golden):
+    g = golden("schedule")
+    cfg = configs.audio_config(CPU)
+    betas, alphas = schedule.make_schedule(cfg.diffusion)
+    assert np.array_equal(betas.numpy(), g["betas"])
+    assert np.array_equal(alphas.numpy(), g["alphas"])  # fp32 cumprod order pinned bit-exactly
+    for name in ("quad", "const", "jsd", "sigmoid"):
+        b = schedule.get_beta_schedule(name, beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)
+        assert np.array_equal(b, g["betas64_" + name])
+    assert schedule.make_seq(1000, 100, "uniform") == g["seq_uniform_100"].tolist()
+    assert schedule.make_seq(1000, 50, "uniform") == g["seq_uniform_50"].tolist()
+    assert schedule.make_seq(1000, 20, "quad") == g["seq_quad_20"].tolist()
+    for warm in (1000, 10000):
+        ours = [ref_cpu.lr_factor(int(s), warm) for s in g["lr_steps"]]
+        assert np.allclose(ours, g[f"lr_factor_{warm}"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("c,hw", [(32, (16, 8)), (64, (5, 7)), (96, (8, 8)), (128, (4, 8)), (192, (3, 5)), (256, (2, 8))])
+def test_residual_block(golden, c, hw):
+    g = golden("blocks")
+    p = f"rb{c}."
+    sd = _sd(_rb_shapes(p, c))
+    x = synth.gaussian(p + "x", (2, c, *hw))
+    temb = synth.gaussian(p + "temb", (2, c)) * 0.5
+    y = ref_cpu.residual_block(sd, p, x, temb)
+    assert rel_err(y, g[f"rb{c}_y"])[0] < TOL
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(32, 64, (8, 16)), (96, 128, (6, 10)), (192, 256, (4, 8))])
+def test_down_up(golden, cin, cout, hw):
+    g = golden("blocks")
+    sd = _sd({f"down{cin}.conv.weight": (cout, cin, 4, 4), f"down{cin}.conv.bias": (cout,),
+              f"up{cout}.conv.weight": (cout, cin, 4, 4), f"up{cout}.conv.bias": (cin,)})
+    yd = ref_cpu.downsample(sd, f"down{cin}.", synth.gaussian(f"down{cin}.x", (2, cin, *hw)))
+    yu = ref_cpu.upsample(sd, f"up{cout}.", synth.gaussian(f"up{cout}.x", (2, cout, hw[0] // 2, hw[1] // 2)))
+    assert rel_err(yd, g[f"down{cin}_y"])[0] < TOL
+    assert rel_err(yu, g[f"up{cout}_y"])[0] < TOL
+
+
+@pytest.fixture(scope="module")
+def audio_state():
+    cfg = configs.audio_config(CPU)
+    return cfg, full_state(cfg)
+
+
+def test_state_inventory_matches_reference(golden, audio_state):
+    g = golden("model")
+    cfg, sd = audio_state
+    assert int(g["n_state_keys"]) == 389 == len(sd)
+    assert list(sd.keys()) == g["state_keys"].tolist()
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == g["state_shapes"].tolist()
+
+
+def test_timestep_table_and_embedding(golden, audio_state):
+    g = golden("model")
+    cfg, sd = audio_state
+    assert np.allclose(sd["temb.te"][[0, 1, 2, 499, 999]].numpy(), g["te_rows"], atol=1e-6)
+    y = ref_cpu.beta_embedding(sd, torch.from_numpy(g["temb_t"]))
+    assert rel_err(y, g["temb_y"])[0] < TOL
+
+
+@pytest.mark.parametrize("s", [4, 32, 96])
+def test_transformer_module(golden, audio_state, s):
+    g = golden("model")
+    cfg, sd = audio_state
+    kw = cfg.model.transformers.kwargs
+    y = ref_cpu.transformer_module(sd, synth.gaussian(f"fnet.x{s}", (1, s, 2048)), kw.num_hidden_layers, kw.layer_norm_eps)
+    assert rel_err(y, g[f"fnet_s{s}_y"])[0] < TOL
+
+
+@pytest.mark.parametrize("tlen", [32, 64])
+def test_model_forward(golden, audio_state, tlen):
+    g = golden("model")
+    cfg, sd = audio_state
+    x = synth.gaussian(f"model.x{tlen}", (2, 2, tlen, 256))
+    with torch.no_grad():
+        y = ref_cpu.model_forward(sd, cfg, x, torch.from_numpy(g[f"model_T{tlen}_t"]))
+    mx, rms = rel_err(y, g[f"model_T{tlen}_y"])
+    assert mx < TOL, (mx, rms)
+
+
+def test_sampler_fake_model(golden):
+    g, gs = golden("sampler"), golden("schedule")
+    alphas = torch.from_numpy(gs["alphas"])
+    fake = lambda x, t: 0.1 * x + 0.01 * t.float().view(-1, 1, 1, 1)  # noqa: E731
+    x = synth.gaussian("sampler.fake.x", (2, 2, 8, 16))
+    for name in ("u10", "quad8"):
+        seq = g[f"samp_{name}_seq"].tolist()
+        for sel_name, sel in (("all", None), ("last", [-1]), ("mix", [0, 3, -2])):
+            xs, x0 = ref_cpu.generalized_steps(x.clone(), seq, fake, alphas, sel, eta=0.0)
+            exs, ex0 = g[f"samp_{name}_{sel_name}_xs"], g[f"samp_{name}_{sel_name}_x0"]
+            assert len(xs) == len(exs) and len(x0) == len(ex0)
+            assert np.array_equal(torch.stack(xs).numpy(), exs)  # same ops, same order: bit-exact
+            assert np.array_equal(torch.stack(x0).numpy(), ex0)
+
+
+def test_sampler_tiny_model_and_training(golden):
+    g, gs = golden("sampler"), golden("schedule")
+    alphas = torch.from_numpy(gs["alphas"])
+    cfg = configs.tiny_config(CPU)
+    sd = full_state(cfg, seed=3)
+    x = synth.gaussian("sampler.tiny.x", (2, 2, 16, 32))
+    with torch.no_grad():
+        y = ref_cpu.model_forward(sd, cfg, x, torch.tensor([7, 901]))
+    assert rel_err(y, g["tiny_model_y"])[0] < TOL
+    calls = []
+
+    def fn(xt, t):
+        calls.append(xt.clone())
+        with torch.no_grad():
+            return ref_cpu.model_forward(sd, cfg, xt, t)
+
+    xs, x0 = ref_cpu.generalized_steps(x.clone(), list(range(0, 1000, 100)), fn, alphas, None, eta=0.0)
+    assert rel_err(torch.stack(calls), g["samp_tiny_inputs"])[0] < 1e-4
+    assert rel_err(torch.stack(xs), g["samp_tiny_xs"])[0] < 1e-4
+    assert rel_err(torch.stack(x0), g["samp_tiny_x0"])[0] < 1e-4
+    # loss / gradient / EMA
+    e = synth.gaussian("train.tiny.e", (2, 2, 16, 32))
+    t = torch.tensor([123, 876])
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "temb.te"}
+    live = dict(params, **{"temb.te": sd["temb.te"]})
+    loss = ref_cpu.noise_estimation_loss(lambda a, b: ref_cpu.model_forward(live, cfg, a, b), x, t, e, alphas)
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-5 * abs(float(g["train_loss"]))
+    per = ref_cpu.noise_estimation_loss(lambda a, b: ref_cpu.model_forward(live, cfg, a, b), x, t, e, alphas, True)
+    assert np.allclose(per.detach().numpy(), g["train_loss_keepdim"], rtol=1e-5)
+    loss.backward()
+    gn = sum(float(p.grad.double().square().sum()) for p in params.values()) ** 0.5
+    assert abs(gn - float(g["train_grad_norm"])) < 1e-4 * float(g["train_grad_norm"])
+    for key in g.files:
+        if key.startswith("train_grad::"):
+            name = key.split("::")[1]
+            ref = g[key]
+            got = params[name].grad.reshape(-1)[:64].numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-12), name
+    shadow = {k: v.detach().clone() for k, v in params.items()}
+    with torch.no_grad():
+        new = {k: v + 0.01 * v.grad for k, v in params.items()}
+    sh = ref_cpu.ema_update(shadow, new, 0.9999)
+    k = "down_modules.0.weight"
+    assert np.allclose(sh[k].reshape(-1)[:64].numpy(), g["ema_shadow::" + k], rtol=1e-6, atol=1e-7)
