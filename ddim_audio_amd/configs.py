@@ -104,12 +104,12 @@ def audio_config(dtype="torch.cuda.FloatTensor", fnet_dtype=None):
 def tiny_dict(dtype="torch.cuda.FloatTensor", fnet_dtype=None):
     """A small network with the same topology rules (verified constructible).
 
-    Channel widths stay multiples of 32 (the MFMA tile) so the HIP path runs it unmodified;
-    f_size 32 with three levels gives an FNet token width of 64 * (32 / 4) = 512.
+    Channel widths are the first three of audio.yml (kernels are instantiated per width pair);
+    f_size 32 with three levels gives an FNet token width of 96 * (32 / 4) = 768.
     """
     d = audio_dict(dtype, fnet_dtype)
     m = d["model"]
-    m["ch"] = [32, 64, 64]
+    m["ch"] = [32, 64, 96]
     m["krn"] = [3, 3, 3]
     m["res"] = [1, 2, 1]
     m["f_size"] = 32

@@ -1,0 +1,25 @@
+// Instantiations of conv_mfma_kernel: DDIMX_DOWNUP_BF16 (see conv_configs.h).
+#include "conv_mfma.h"
+#include "conv_configs.h"
+
+namespace ddimx {
+
+#define DDIMX_GEOM(T, CIN, NOUT, NB, MODE, TH, TW, WM, WN, KC, TPC)                  \
+    if (mode == MODE && cin == CIN && nout == NOUT) {                               \
+        g->th = TH; g->tw = TW; g->nb = NB; g->nout = NOUT; g->classes = (MODE == UP4 ? 2 : 1); \
+        return hipSuccess;                                                          \
+    }
+#define DDIMX_LAUNCH(T, CIN, NOUT, NB, MODE, TH, TW, WM, WN, KC, TPC)                \
+    if (mode == MODE && cin == CIN && nout == NOUT)                                 \
+        return launch_conv_cfg<ConvCfg<T, CIN, NOUT, NB, MODE, TH, TW, WM, WN, KC, TPC>>(a, stream);
+
+hipError_t conv_geometry_bf16_du(int mode, int cin, int nout, ConvGeom* g) {
+    DDIMX_DOWNUP_BF16(DDIMX_GEOM)
+    return hipErrorInvalidValue;
+}
+hipError_t conv_launch_bf16_du(int mode, int cin, int nout, ConvArgs& a, hipStream_t stream) {
+    DDIMX_DOWNUP_BF16(DDIMX_LAUNCH)
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ddimx

@@ -1,0 +1,82 @@
+// Launch wrappers of the non-MFMA kernels (kernels.hip) and the fp32 MFMA GEMM (gemm_f32.hip).
+// All enqueue on the given stream, never allocate or synchronise (graph-capturable).
+#pragma once
+#include "common.h"
+
+namespace ddimx {
+
+// ---- U-Net edge convolutions (C_io = 2 side; HBM-bound; layout conversion NCHW fp32 <-> NHWC T) ----
+// in-conv: reference models/diffusion.py:189-198.  x [B][2][H][W] fp32 -> out [B][H][W][C0] T, + stats partials
+hipError_t conv_in_launch(int dtype, const float* x, const float* w /*[C0][cin][3][3]*/, const float* bias, void* out,
+                          float* stats, int B, int cin, int C0, int H, int W, hipStream_t s);
+int conv_in_nparts(int H, int W);
+// out-conv: models/diffusion.py:199-208 preceded by x + hidden[0] (:284).  (a + b) NHWC T -> eps [B][cout][H][W] fp32
+hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float* w /*[cout][C0][3][3]*/,
+                           const float* bias, float* out, int B, int C0, int cout, int H, int W, hipStream_t s);
+
+// ---- GroupNorm statistics -> folded per-(sample, channel) scale / shift ---------------------------
+// stats [B][nparts][Cs][2]; channel vc of the slab is real channel vc % C.  count = elements per group.
+hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, double count, const float* gamma,
+                              const float* beta /*nullable*/, float eps, float* scale, float* shift, int B,
+                              hipStream_t s);
+
+// ---- residual pass: y = x + (h*scale + shift)  (block tail, models/diffusion.py:54-56), or y = x + h ----
+// h_f32: h is fp32 (FNet output) and no affine is applied.  stats nullable.  Elements per sample = HW*C.
+hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, const float* scale, const float* shift,
+                        void* y, float* stats, int B, int HW, int C, hipStream_t s);
+int resid_nparts(int dtype, int HW, int C);
+// per-channel (sum, sumsq) partials of an NHWC tensor, same partitioning as resid_nparts
+hipError_t tensor_stats_launch(int dtype, const void* x, float* stats, int B, int HW, int C, hipStream_t s);
+hipError_t to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int HW, hipStream_t s);
+hipError_t from_nhwc_launch(int dtype, const void* in, float* out, int B, int C, int HW, hipStream_t s);
+
+// ---- small dense layers (timestep embedding MLP, models/diffusion.py:110-120) ------------------------
+// y[b][n] = act(sum_k x[row(b)][k] * W[n][k] + bias[n]); row(b) = idx ? idx[b] : b
+hipError_t linear_rows_launch(const float* x, const int64_t* idx, const float* W, const float* bias, float* y, int B,
+                              int N, int K, int act_silu, hipStream_t s);
+
+// ---- LayerNorm over rows -----------------------------------------------------------------------------
+// y = LN(x [+ add[(m % add_rows)]]) * gamma + beta;  x is T (dtype) or fp32 (dtype = DT_F32)
+hipError_t layernorm_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma,
+                            const float* beta, float eps, float* y, int M, int N, hipStream_t s);
+
+// ---- fp32 GEMM on v_mfma_f32_32x32x2_f32: C[z][M][N] (+)= A[z][M][K] * B[z][N][K]^T ----------------------
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;      // [N] or null
+    const float* resid;     // [M][N] (ldc) added in the epilogue, or null
+    int M, N, K, lda, ldb, ldc;
+    long long sA, sB, sC;   // batch strides (elements); batch = grid.z
+    int batch;
+    int accumulate;         // C += ...
+    int act;                // 0 none, 1 gelu_new
+};
+hipError_t gemm_f32_launch(const GemmArgs& g, hipStream_t s);
+
+// ---- sampler / training elementwise ------------------------------------------------------------------
+// coef rows: (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1) fp32; step is a device counter
+hipError_t step_begin_launch(const float* coef, const int* step, int64_t* t, int B, hipStream_t s);
+hipError_t step_end_launch(int* step, hipStream_t s);
+hipError_t ddim_update_launch(float* xt, const float* et, const float* noise, float* x0, const float* coef,
+                              const int* step, long long n, hipStream_t s);
+hipError_t qsample_launch(const float* x0, const float* e, const float* alphas, const int64_t* t, float* x, int B,
+                          long long per, hipStream_t s);
+hipError_t sqerr_launch(const float* e, const float* out, float* partial, float* loss_per, int B, long long per,
+                        hipStream_t s);
+int sqerr_nparts();
+hipError_t ema_multi_launch(const long long* shadow_ptrs, const long long* param_ptrs, const long long* sizes,
+                            const int* blk_tensor, const long long* blk_off, int nblocks, float mu, hipStream_t s);
+int ema_block_elems();
+
+// ---- weight packing ------------------------------------------------------------------------------------
+hipError_t pack_copy_launch(const float* src, float* dst, long long n, hipStream_t s);
+hipError_t pack_conv_launch(int dtype, const float* w /*[O][I][KH][KW]*/, void* dst /*[KH*KW][O][I]*/, int O, int I,
+                            int KH, int KW, hipStream_t s);
+hipError_t pack_convT_launch(int dtype, const float* w /*[I][O][4][4]*/, void* dst /*[2][6][2*O][I]*/, int I, int O,
+                             hipStream_t s);
+// dst[r][f*C + c] = src[r][c*Fr + f]   (token-order permutation of the FNet boundary, rows r)
+hipError_t pack_perm_cols_launch(const float* src, float* dst, int rows, int C, int Fr, hipStream_t s);
+// dst[(f*C + c)][k] = src[(c*Fr + f)][k]
+hipError_t pack_perm_rows_launch(const float* src, float* dst, int C, int Fr, int K, hipStream_t s);
+
+}  // namespace ddimx

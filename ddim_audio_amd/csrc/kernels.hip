@@ -1,0 +1,708 @@
+// Non-MFMA kernels of libddimx: HBM-bound edge convolutions, GroupNorm finalisation, the residual
+// pass, small dense layers, LayerNorm, sampler / loss / EMA elementwise kernels and weight packing.
+// gfx950 only.  Every reduction is a fixed-order tree (no float atomics): results are reproducible.
+#include "kernels.h"
+
+namespace ddimx {
+
+// =====================================================================================================
+// in-conv: Conv2d(cin -> C0, k3, p1) reading NCHW fp32, writing NHWC T (+ per-channel stats partials)
+// =====================================================================================================
+constexpr int kInPixPerBlock = 1024;
+int conv_in_nparts(int H, int W) { return (H * W + kInPixPerBlock - 1) / kInPixPerBlock; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, T* __restrict__ out,
+                                                      float* __restrict__ stats, int cin, int C0, int H, int W) {
+    constexpr int EPB = Piece<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;                       // [cin*9][C0]
+    float* red = lds + cin * 9 * C0;       // [4 waves][C0][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OPP = C0 / EPB, PPP = 256 / OPP;
+    const int b = blockIdx.y, part = blockIdx.x;
+    for (int i = tid; i < cin * 9 * C0; i += 256) {
+        const int co = i % C0, r = i / C0;  // r = ci*9 + tap
+        wl[i] = w[(size_t)co * cin * 9 + r];
+    }
+    __syncthreads();
+    const int c = tid % OPP, pslot = tid / OPP;
+    float s[EPB], q[EPB], bv[EPB];
+#pragma unroll
+    for (int j = 0; j < EPB; ++j) { s[j] = q[j] = 0.f; bv[j] = bias[c * EPB + j]; }
+    const int HW = H * W;
+    const float* xb = x + (size_t)b * cin * HW;
+    for (int it = 0; it < kInPixPerBlock / PPP; ++it) {
+        const int pix = part * kInPixPerBlock + it * PPP + pslot;
+        if (pix >= HW) break;
+        const int py = pix / W, px = pix % W;
+        float acc[EPB];
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) acc[j] = bv[j];
+        for (int ci = 0; ci < cin; ++ci) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int gy = py + k / 3 - 1, gx = px + k % 3 - 1;
+                float v = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = xb[(size_t)ci * HW + (size_t)gy * W + gx];
+                const float* wr = wl + (ci * 9 + k) * C0 + c * EPB;
+#pragma unroll
+                for (int j = 0; j < EPB; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+            }
+        }
+        uint4 pv = Piece<T>::pack(acc);
+        Piece<T>::unpack(pv, acc);  // statistics of the stored values
+        *(uint4*)(out + ((size_t)b * HW + pix) * C0 + c * EPB) = pv;
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) { s[j] += acc[j]; q[j] = fmaf(acc[j], acc[j], q[j]); }
+    }
+    if (stats) {
+        for (int o = OPP; o < 64; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+        }
+        if (lane < OPP) {
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) {
+                red[(wave * C0 + c * EPB + j) * 2 + 0] = s[j];
+                red[(wave * C0 + c * EPB + j) * 2 + 1] = q[j];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < C0 * 2; i += 256) {
+            const float t = red[i] + red[C0 * 2 + i] + red[2 * C0 * 2 + i] + red[3 * C0 * 2 + i];
+            stats[(((size_t)b * gridDim.x + part) * C0) * 2 + i] = t;
+        }
+    }
+}
+
+hipError_t conv_in_launch(int dtype, const float* x, const float* w, const float* bias, void* out, float* stats, int B,
+                          int cin, int C0, int H, int W, hipStream_t s) {
+    const int epb = dtype == DT_BF16 ? 8 : 4;
+    const int opp = C0 / epb;
+    if (C0 % epb || opp > 64 || (opp & (opp - 1))) return hipErrorInvalidValue;
+    dim3 grid(conv_in_nparts(H, W), B);
+    const size_t lds = (size_t)(cin * 9 * C0 + 4 * C0 * 2) * 4;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(conv_in_kernel<__bf16>, grid, dim3(256), lds, s, x, w, bias, (__bf16*)out, stats, cin, C0, H, W);
+    else
+        hipLaunchKernelGGL(conv_in_kernel<float>, grid, dim3(256), lds, s, x, w, bias, (float*)out, stats, cin, C0, H, W);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// out-conv: Conv2d(C0 -> cout, k3, p1) on (a + b) NHWC T, writing NCHW fp32
+// =====================================================================================================
+constexpr int kOutTH = 8, kOutTW = 32;
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv_out_kernel(const T* __restrict__ a, const T* __restrict__ b2,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int C0, int cout, int H, int W,
+                                                       int tiles_x, int tiles_y) {
+    constexpr int EPB = Piece<T>::N;
+    constexpr int IH = kOutTH + 2, IW = kOutTW + 2;
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [IH*IW][C0+1]
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = ty * kOutTH, x0 = tx * kOutTW;
+    const int CPP = C0 / EPB, LS = C0 + 1;
+    for (int i = tid; i < IH * IW * CPP; i += 256) {
+        const int c = i % CPP, pix = i / CPP;
+        const int gy = y0 - 1 + pix / IW, gx = x0 - 1 + pix % IW;
+        float f[EPB];
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) f[j] = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t g = (((size_t)b * H + gy) * W + gx) * C0 + c * EPB;
+            float k[EPB];
+            Piece<T>::unpack(*(const uint4*)(a + g), f);
+            Piece<T>::unpack(*(const uint4*)(b2 + g), k);
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) f[j] += k[j];  // x + hidden[0], kept in fp32
+        }
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) tile[pix * LS + c * EPB + j] = f[j];
+    }
+    __syncthreads();
+    const int py = tid / kOutTW, px = tid % kOutTW;
+    float acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = (o < cout) ? bias[o] : 0.f;
+    for (int ci = 0; ci < C0; ++ci) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float v = tile[((py + k / 3) * IW + px + k % 3) * LS + ci];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < cout) acc[o] = fmaf(v, w[((size_t)o * C0 + ci) * 9 + k], acc[o]);
+        }
+    }
+    const int gy = y0 + py, gx = x0 + px;
+    if (gy < H && gx < W) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < cout) out[(((size_t)b * cout + o) * H + gy) * W + gx] = acc[o];
+    }
+}
+
+hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float* w, const float* bias, float* out, int B,
+                           int C0, int cout, int H, int W, hipStream_t s) {
+    if (cout > 4 || C0 % 8) return hipErrorInvalidValue;
+    const int tiles_x = (W + kOutTW - 1) / kOutTW, tiles_y = (H + kOutTH - 1) / kOutTH;
+    const size_t lds = (size_t)(kOutTH + 2) * (kOutTW + 2) * (C0 + 1) * 4;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    dim3 grid(tiles_x * tiles_y * B);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(conv_out_kernel<__bf16>, grid, dim3(256), lds, s, (const __bf16*)a, (const __bf16*)b, w, bias,
+                           out, C0, cout, H, W, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(conv_out_kernel<float>, grid, dim3(256), lds, s, (const float*)a, (const float*)b, w, bias, out,
+                           C0, cout, H, W, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// GroupNorm finalisation: partial (sum, sumsq) slabs -> per-(sample, channel) scale / shift
+//   scale = rstd_g * gamma_c ; shift = beta_c - mean_g * scale     (torch.nn.GroupNorm, biased variance)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ stats, int nparts, int Cs, int C,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double rs[4], rq[4];
+    __shared__ float mr[2];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int GS = C / kGroups, reps = Cs / C;
+    const int per_part = reps * GS;
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < nparts * per_part; i += 256) {
+        const int part = i / per_part, r = i % per_part;
+        const int vc = (r / GS) * C + g * GS + r % GS;
+        const float* p = stats + (((size_t)b * nparts + part) * Cs + vc) * 2;
+        s += (double)p[0];
+        q += (double)p[1];
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if ((tid & 63) == 0) { rs[tid >> 6] = s; rq[tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        const double S = rs[0] + rs[1] + rs[2] + rs[3], Q = rq[0] + rq[1] + rq[2] + rq[3];
+        const double mean = S / count;
+        double var = Q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[0] = (float)mean;
+        mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int i = tid; i < GS; i += 256) {
+        const int c = g * GS + i;
+        const float sc = mr[1] * gamma[c];
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = (beta ? beta[c] : 0.f) - mr[0] * sc;
+    }
+}
+
+hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, double count, const float* gamma,
+                              const float* beta, float eps, float* scale, float* shift, int B, hipStream_t s) {
+    if (C % kGroups || Cs % C) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(kGroups, B), dim3(256), 0, s, stats, nparts, Cs, C, count, gamma, beta,
+                       eps, scale, shift);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// residual pass: y = x + (h*scale + shift)   or   y = x + h(fp32)
+// =====================================================================================================
+constexpr int kResidIters = 16;
+static inline int resid_bd(int cpp) { return (cpp % 3 == 0) ? 192 : 256; }
+int resid_nparts(int dtype, int HW, int C) {
+    const int epb = dtype == DT_BF16 ? 8 : 4;
+    const int cpp = C / epb;
+    const long long pieces = (long long)HW * cpp;
+    const int per_block = resid_bd(cpp) * kResidIters;
+    return (int)((pieces + per_block - 1) / per_block);
+}
+
+template <typename T, bool HF32>
+__global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __restrict__ hv,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    T* y, float* __restrict__ stats, int HW, int C) {
+    constexpr int EPB = Piece<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [R][C*2]
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int CPP = C / EPB;
+    const int c = tid % CPP;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const long long pieces = (long long)HW * CPP;
+    float sc[EPB], sh[EPB], s[EPB], q[EPB];
+#pragma unroll
+    for (int j = 0; j < EPB; ++j) {
+        s[j] = q[j] = 0.f;
+        sc[j] = HF32 ? 1.f : scale[(size_t)b * C + c * EPB + j];
+        sh[j] = HF32 ? 0.f : shift[(size_t)b * C + c * EPB + j];
+    }
+    const size_t sbase = (size_t)b * HW * C;
+    for (int it = 0; it < kResidIters; ++it) {
+        const long long pc = ((long long)part * kResidIters + it) * bd + tid;
+        if (pc >= pieces) break;
+        const size_t e = sbase + (size_t)pc * EPB;
+        float fx[EPB], fh[EPB];
+        Piece<T>::unpack(*(const uint4*)(x + e), fx);
+        if constexpr (HF32) {
+            const float* hp = (const float*)hv + e;
+#pragma unroll
+            for (int j = 0; j < EPB; j += 4) {
+                const float4 t = *(const float4*)(hp + j);
+                fh[j] = t.x; fh[j + 1] = t.y; fh[j + 2] = t.z; fh[j + 3] = t.w;
+            }
+        } else {
+            Piece<T>::unpack(*(const uint4*)((const T*)hv + e), fh);
+        }
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) fx[j] = fx[j] + fmaf(fh[j], sc[j], sh[j]);
+        const uint4 pv = Piece<T>::pack(fx);
+        *(uint4*)(y + e) = pv;
+        Piece<T>::unpack(pv, fx);
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) { s[j] += fx[j]; q[j] = fmaf(fx[j], fx[j], q[j]); }
+    }
+    if (stats) {
+        const int R = bd / CPP, row = tid / CPP;
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) {
+            red[(row * C + c * EPB + j) * 2 + 0] = s[j];
+            red[(row * C + c * EPB + j) * 2 + 1] = q[j];
+        }
+        __syncthreads();
+        for (int i = tid; i < C * 2; i += bd) {
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += red[r * C * 2 + i];
+            stats[(((size_t)b * gridDim.x + part) * C) * 2 + i] = t;
+        }
+    }
+}
+
+hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, const float* scale, const float* shift,
+                        void* y, float* stats, int B, int HW, int C, hipStream_t s) {
+    const int epb = dtype == DT_BF16 ? 8 : 4;
+    if (C % epb) return hipErrorInvalidValue;
+    const int cpp = C / epb, bd = resid_bd(cpp);
+    if (bd % cpp) return hipErrorInvalidValue;
+    dim3 grid(resid_nparts(dtype, HW, C), B);
+    const size_t lds = stats ? (size_t)(bd / cpp) * C * 2 * 4 : 0;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+#define DDIMX_RESID(TT, HF)                                                                                     \
+    hipLaunchKernelGGL((resid_kernel<TT, HF>), grid, dim3(bd), lds, s, (const TT*)x, h, scale, shift, (TT*)y, stats, HW, C)
+    if (dtype == DT_BF16) { if (h_f32) DDIMX_RESID(__bf16, true); else DDIMX_RESID(__bf16, false); }
+    else { if (h_f32) DDIMX_RESID(float, true); else DDIMX_RESID(float, false); }
+#undef DDIMX_RESID
+    return hipGetLastError();
+}
+
+
+// ---- per-channel statistics of an NHWC tensor (used when a tensor arrives without producer stats) ----
+template <typename T>
+__global__ void __launch_bounds__(256) tensor_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int HW,
+                                                           int C) {
+    constexpr int EPB = Piece<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int CPP = C / EPB, c = tid % CPP, b = blockIdx.y, part = blockIdx.x;
+    const long long pieces = (long long)HW * CPP;
+    float s[EPB], q[EPB];
+#pragma unroll
+    for (int j = 0; j < EPB; ++j) s[j] = q[j] = 0.f;
+    for (int it = 0; it < kResidIters; ++it) {
+        const long long pc = ((long long)part * kResidIters + it) * bd + tid;
+        if (pc >= pieces) break;
+        float f[EPB];
+        Piece<T>::unpack(*(const uint4*)(x + (size_t)b * HW * C + (size_t)pc * EPB), f);
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+    }
+    const int R = bd / CPP, row = tid / CPP;
+#pragma unroll
+    for (int j = 0; j < EPB; ++j) {
+        red[(row * C + c * EPB + j) * 2 + 0] = s[j];
+        red[(row * C + c * EPB + j) * 2 + 1] = q[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < C * 2; i += bd) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += red[r * C * 2 + i];
+        stats[(((size_t)b * gridDim.x + part) * C) * 2 + i] = t;
+    }
+}
+hipError_t tensor_stats_launch(int dtype, const void* x, float* stats, int B, int HW, int C, hipStream_t s) {
+    const int epb = dtype == DT_BF16 ? 8 : 4;
+    if (C % epb) return hipErrorInvalidValue;
+    const int cpp = C / epb, bd = resid_bd(cpp);
+    if (bd % cpp) return hipErrorInvalidValue;
+    dim3 grid(resid_nparts(dtype, HW, C), B);
+    const size_t lds = (size_t)(bd / cpp) * C * 2 * 4;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(tensor_stats_kernel<__bf16>, grid, dim3(bd), lds, s, (const __bf16*)x, stats, HW, C);
+    else hipLaunchKernelGGL(tensor_stats_kernel<float>, grid, dim3(bd), lds, s, (const float*)x, stats, HW, C);
+    return hipGetLastError();
+}
+
+// ---- layout converters (test / boundary helpers) -------------------------------------------------------
+template <typename T>
+__global__ void to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int C, int HW, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = i % C;
+        const long long p = (i / C) % HW, b = i / ((long long)C * HW);
+        out[i] = from_f<T>(in[(b * C + c) * HW + p]);
+    }
+}
+template <typename T>
+__global__ void from_nhwc_kernel(const T* __restrict__ in, float* __restrict__ out, int C, int HW, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW;
+        const int c = (i / HW) % C;
+        const long long b = i / ((long long)C * HW);
+        out[i] = to_f<T>(in[(b * HW + p) * C + c]);
+    }
+}
+hipError_t to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int HW, hipStream_t s) {
+    const long long n = (long long)B * C * HW;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(to_nhwc_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, in, (__bf16*)out, C, HW, n);
+    else hipLaunchKernelGGL(to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, s, in, (float*)out, C, HW, n);
+    return hipGetLastError();
+}
+hipError_t from_nhwc_launch(int dtype, const void* in, float* out, int B, int C, int HW, hipStream_t s) {
+    const long long n = (long long)B * C * HW;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(from_nhwc_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)in, out, C, HW, n);
+    else hipLaunchKernelGGL(from_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)in, out, C, HW, n);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// small dense layer: one wave per output feature, all batch rows at once (weight-bandwidth bound)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) linear_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int B, int N, int K, int act) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* wr = W + (size_t)n * K;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 wv = *(const float4*)(wr + k);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (b0 + r < B) {
+                    const size_t row = idx ? (size_t)idx[b0 + r] : (size_t)(b0 + r);
+                    const float4 xv = *(const float4*)(x + row * K + k);
+                    acc[r] = fmaf(xv.x, wv.x, acc[r]); acc[r] = fmaf(xv.y, wv.y, acc[r]);
+                    acc[r] = fmaf(xv.z, wv.z, acc[r]); acc[r] = fmaf(xv.w, wv.w, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float t = wave_sum(acc[r]);
+            if (lane == 0 && b0 + r < B) {
+                const float v = t + bias[n];
+                y[(size_t)(b0 + r) * N + n] = act ? silu_f(v) : v;
+            }
+        }
+    }
+}
+
+hipError_t linear_rows_launch(const float* x, const int64_t* idx, const float* W, const float* bias, float* y, int B,
+                              int N, int K, int act_silu, hipStream_t s) {
+    if (K % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, idx, W, bias, y, B, N, K, act_silu);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// LayerNorm over rows (two-pass in registers: mean, then centred variance)
+// =====================================================================================================
+template <typename TX>
+__global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x, const float* __restrict__ add,
+                                                        int add_rows, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ y, int N) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const TX* xr = x + (size_t)m * N;
+    const float* ar = add ? add + (size_t)(m % add_rows) * N : nullptr;
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        v[i] = 0.f;
+        if (n < N) { v[i] = to_f<TX>(xr[n]) + (ar ? ar[n] : 0.f); s += v[i]; }
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) bc = (red[0] + red[1] + red[2] + red[3]) / (float)N;
+    __syncthreads();
+    const float mean = bc;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        if (n < N) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    }
+    q = wave_sum(q);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) bc = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
+    __syncthreads();
+    const float rstd = bc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        if (n < N) y[(size_t)m * N + n] = (v[i] - mean) * rstd * gamma[n] + beta[n];
+    }
+}
+
+hipError_t layernorm_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma,
+                            const float* beta, float eps, float* y, int M, int N, hipStream_t s) {
+    if (N > 2048) return hipErrorInvalidValue;
+    if (x_dtype == DT_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<__bf16>, dim3(M), dim3(256), 0, s, (const __bf16*)x, add, add_rows, gamma, beta,
+                           eps, y, N);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)x, add, add_rows, gamma, beta,
+                           eps, y, N);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// sampler step kernels (functions/denoising.py:22-43): scalars come from a device table indexed by a
+// device step counter, so a captured graph can be replayed for every step.
+// =====================================================================================================
+__global__ void step_begin_kernel(const float* __restrict__ coef, const int* __restrict__ step, int64_t* __restrict__ t,
+                                  int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) t[i] = (int64_t)coef[(size_t)step[0] * 6];
+}
+__global__ void step_end_kernel(int* step) { step[0] += 1; }
+
+hipError_t step_begin_launch(const float* coef, const int* step, int64_t* t, int B, hipStream_t s) {
+    hipLaunchKernelGGL(step_begin_kernel, dim3((B + 63) / 64), dim3(64), 0, s, coef, step, t, B);
+    return hipGetLastError();
+}
+hipError_t step_end_launch(int* step, hipStream_t s) {
+    hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, s, step);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) ddim_update_kernel(float* __restrict__ xt, const float* __restrict__ et,
+                                                          const float* __restrict__ noise, float* __restrict__ x0,
+                                                          const float* __restrict__ coef, const int* __restrict__ step,
+                                                          long long n4) {
+    const float* c = coef + (size_t)step[0] * 6;
+    const float s1 = c[1], s2 = c[2], s3 = c[3], c2 = c[4], c1 = c[5];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 x = ((const float4*)xt)[i];
+        const float4 e = ((const float4*)et)[i];
+        float xs[4] = {x.x, x.y, x.z, x.w};
+        const float es[4] = {e.x, e.y, e.z, e.w};
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (noise) { const float4 z = ((const float4*)noise)[i]; nz[0] = z.x; nz[1] = z.y; nz[2] = z.z; nz[3] = z.w; }
+        float p0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // xt.add_(et, alpha=-sqrt(1-at)).div_(sqrt(at))  -> x0 prediction, in place
+            const float v = __fdiv_rn(fmaf(es[j], -s1, xs[j]), s2);
+            p0[j] = v;
+            // xt.mul_(sqrt(at_next)).add_(et, alpha=c2).add_(noise, alpha=c1)
+            float u = fmaf(es[j], c2, __fmul_rn(v, s3));
+            if (noise) u = fmaf(nz[j], c1, u);
+            xs[j] = u;
+        }
+        ((float4*)x0)[i] = make_float4(p0[0], p0[1], p0[2], p0[3]);
+        ((float4*)xt)[i] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+    }
+}
+
+hipError_t ddim_update_launch(float* xt, const float* et, const float* noise, float* x0, const float* coef,
+                              const int* step, long long n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const long long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(blocks), dim3(256), 0, s, xt, et, noise, x0, coef, step, n4);
+    return hipGetLastError();
+}
+
+// ---- q-sample (functions/losses.py:12-13): x = x0*sqrt(a_t) + e*sqrt(1-a_t), separate fp32 roundings ----
+__global__ void __launch_bounds__(256) qsample_kernel(const float* __restrict__ x0, const float* __restrict__ e,
+                                                      const float* __restrict__ alphas, const int64_t* __restrict__ t,
+                                                      float* __restrict__ x, long long per) {
+    const int b = blockIdx.y;
+    const float a = alphas[t[b]];
+    const float sa = __fsqrt_rn(a), sb = __fsqrt_rn(__fsub_rn(1.0f, a));
+    const size_t base = (size_t)b * per;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)gridDim.x * 256)
+        x[base + i] = __fadd_rn(__fmul_rn(x0[base + i], sa), __fmul_rn(e[base + i], sb));
+}
+hipError_t qsample_launch(const float* x0, const float* e, const float* alphas, const int64_t* t, float* x, int B,
+                          long long per, hipStream_t s) {
+    const int blocks = (int)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024);
+    hipLaunchKernelGGL(qsample_kernel, dim3(blocks, B), dim3(256), 0, s, x0, e, alphas, t, x, per);
+    return hipGetLastError();
+}
+
+// ---- loss (functions/losses.py:15-18): per-sample sum of squared error, then batch mean --------------
+constexpr int kSqParts = 64;
+int sqerr_nparts() { return kSqParts; }
+__global__ void __launch_bounds__(256) sqerr_part_kernel(const float* __restrict__ e, const float* __restrict__ o,
+                                                         float* __restrict__ partial, long long per) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, part = blockIdx.x;
+    const long long chunk = (per + kSqParts - 1) / kSqParts;
+    const long long lo = part * chunk, hi = (lo + chunk < per) ? lo + chunk : per;
+    const size_t base = (size_t)b * per;
+    float s = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) { const float d = e[base + i] - o[base + i]; s = fmaf(d, d, s); }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[b * kSqParts + part] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sqerr_final_kernel(const float* __restrict__ partial, float* __restrict__ loss, int B) {
+    // one wave: loss[b] = sum of parts; loss[B] = mean over the batch
+    const int lane = threadIdx.x;
+    float tot = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float v = wave_sum(lane < kSqParts ? partial[b * kSqParts + lane] : 0.f);
+        if (lane == 0) loss[b] = v;
+        tot += v;
+    }
+    if (lane == 0) loss[B] = tot / (float)B;
+}
+hipError_t sqerr_launch(const float* e, const float* out, float* partial, float* loss_per, int B, long long per,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(sqerr_part_kernel, dim3(kSqParts, B), dim3(256), 0, s, e, out, partial, per);
+    hipLaunchKernelGGL(sqerr_final_kernel, dim3(1), dim3(64), 0, s, partial, loss_per, B);
+    return hipGetLastError();
+}
+
+// ---- EMA (models/ema.py:16-23): shadow = (1-mu)*p + mu*shadow over all tensors in one launch ----------
+constexpr int kEmaBlock = 4096;
+int ema_block_elems() { return kEmaBlock; }
+__global__ void __launch_bounds__(256) ema_multi_kernel(const long long* __restrict__ shadow_ptrs,
+                                                        const long long* __restrict__ param_ptrs,
+                                                        const long long* __restrict__ sizes,
+                                                        const int* __restrict__ blk_tensor,
+                                                        const long long* __restrict__ blk_off, float c_p, float c_s) {
+    const int ti = blk_tensor[blockIdx.x];
+    float* sh = (float*)shadow_ptrs[ti];
+    const float* p = (const float*)param_ptrs[ti];
+    const long long n = sizes[ti], off = blk_off[blockIdx.x];
+    for (int i = threadIdx.x; i < kEmaBlock; i += 256) {
+        const long long k = off + i;
+        if (k < n) sh[k] = __fadd_rn(__fmul_rn(c_p, p[k]), __fmul_rn(c_s, sh[k]));
+    }
+}
+hipError_t ema_multi_launch(const long long* shadow_ptrs, const long long* param_ptrs, const long long* sizes,
+                            const int* blk_tensor, const long long* blk_off, int nblocks, float mu, hipStream_t s) {
+    const float c_p = (float)(1.0 - (double)mu);
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(nblocks), dim3(256), 0, s, shadow_ptrs, param_ptrs, sizes, blk_tensor,
+                       blk_off, c_p, mu);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// weight packing (fp32 parameters -> internal layouts)
+// =====================================================================================================
+__global__ void pack_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+hipError_t pack_copy_launch(const float* src, float* dst, long long n, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(pack_copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ dst, int O, int I, int KK) {
+    const long long n = (long long)KK * O * I;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int ci = i % I, co = (i / I) % O, tap = i / ((long long)I * O);
+        dst[i] = from_f<T>(w[((size_t)co * I + ci) * KK + tap]);
+    }
+}
+hipError_t pack_conv_launch(int dtype, const float* w, void* dst, int O, int I, int KH, int KW, hipStream_t s) {
+    const long long n = (long long)KH * KW * O * I;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(pack_conv_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, w, (__bf16*)dst, O, I, KH * KW);
+    else hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)dst, O, I, KH * KW);
+    return hipGetLastError();
+}
+
+// ConvTranspose2d(k4,s2,p1) weight [I][O][4][4] -> sub-pixel form [a][tap=(dyi,dx)][vc=b*O+co][ci]:
+// output (2py+a, 2px+b) reads input (py+dy-1, px+dx-1) through kernel element kh = 3+a-2dy, kw = 3+b-2dx
+// (dy = a+dyi in {a,a+1}; dx in {0,1,2}); combinations whose kw falls outside 0..3 are zero.
+template <typename T>
+__global__ void pack_convT_kernel(const float* __restrict__ w, T* __restrict__ dst, int I, int O) {
+    const long long n = 2LL * 6 * 2 * O * I;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int ci = i % I;
+        const int vc = (i / I) % (2 * O);
+        const int tap = (i / ((long long)I * 2 * O)) % 6;
+        const int a = i / ((long long)I * 2 * O * 6);
+        const int b = vc / O, co = vc % O;
+        const int dy = a + tap / 3, dx = tap % 3;
+        const int kh = 3 + a - 2 * dy, kw = 3 + b - 2 * dx;
+        float v = 0.f;
+        if (kw >= 0 && kw < 4 && kh >= 0 && kh < 4) v = w[(((size_t)ci * O + co) * 4 + kh) * 4 + kw];
+        dst[i] = from_f<T>(v);
+    }
+}
+hipError_t pack_convT_launch(int dtype, const float* w, void* dst, int I, int O, hipStream_t s) {
+    const long long n = 2LL * 6 * 2 * O * I;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(pack_convT_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, w, (__bf16*)dst, I, O);
+    else hipLaunchKernelGGL(pack_convT_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)dst, I, O);
+    return hipGetLastError();
+}
+
+__global__ void pack_perm_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int Fr) {
+    const long long n = (long long)rows * C * Fr;
+    const int Wd = C * Fr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int col = i % Wd;
+        const long long r = i / Wd;
+        const int f = col / C, c = col % C;
+        dst[i] = src[r * Wd + (long long)c * Fr + f];
+    }
+}
+hipError_t pack_perm_cols_launch(const float* src, float* dst, int rows, int C, int Fr, hipStream_t s) {
+    const long long n = (long long)rows * C * Fr;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_perm_cols_kernel, dim3(blocks), dim3(256), 0, s, src, dst, rows, C, Fr);
+    return hipGetLastError();
+}
+__global__ void pack_perm_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int Fr, int K) {
+    const long long n = (long long)C * Fr * K;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int k = i % K;
+        const int row = i / K;
+        const int f = row / C, c = row % C;
+        dst[i] = src[((long long)c * Fr + f) * K + k];
+    }
+}
+hipError_t pack_perm_rows_launch(const float* src, float* dst, int C, int Fr, int K, hipStream_t s) {
+    const long long n = (long long)C * Fr * K;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_perm_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, C, Fr, K);
+    return hipGetLastError();
+}
+
+}  // namespace ddimx

@@ -116,8 +116,6 @@ def _default_init_(name, p):
                 p.fill_(1.0)
             return
         if p.dim() == 4:
-            transposed = name.startswith("up_modules") and ".conv.weight" in name
-            fan_in = (p.shape[0] if not transposed else p.shape[1]) if False else None
             # torch's fan_in convention is shape[1]*k*k for both Conv2d and ConvTranspose2d weights
             fan_in = p.shape[1] * p.shape[2] * p.shape[3]
         elif p.dim() == 2:
@@ -166,3 +164,190 @@ def build_parameters(root, config):
                 b = 1.0 / math.sqrt(fan[owner])
                 p.uniform_(-b, b)
     return inv
+
+
+# ---------------------------------------------------------------------------------------------------
+def _posenc_table(s, width, c_last, fr):
+    """Add_Encoding table of TransformerEmbedding (reference models/diffusion.py:81-92,131-140): built
+    on the host with the reference's op order for a power-of-two-rounded length, sliced to S (any
+    order of S works; the reference's inverted cache test does not -- SURVEY section 5), then permuted
+    from the reference token order (c*Fr + f) to the library's NHWC order (f*C + c)."""
+    size = 2 ** math.ceil(math.log2(s)) if s > 1 else 1
+    pos = torch.arange(size, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, width, 2, dtype=torch.float32) * (-math.log(10000.0) / width))
+    pe = torch.zeros(size, width)
+    pe[:, 0::2] += torch.sin(pos * div)
+    pe[:, 1::2] += torch.cos(pos * div)
+    return pe[:s].reshape(s, c_last, fr).permute(0, 2, 1).reshape(s, width).contiguous()
+
+
+def _dft_tables(n):
+    """cos / sin of 2*pi*k*m/n in float64, rounded once to fp32 (argument reduced exactly mod n)."""
+    import numpy as np
+    k = np.arange(n, dtype=np.int64)
+    ang = 2.0 * np.pi * ((k[:, None] * k[None, :]) % n).astype(np.float64) / n
+    return np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+
+
+class Model(_Node):
+    """Drop-in for reference ``models.diffusion.Model`` (``models/diffusion.py:170-294``)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config.model  # same attribute as the reference (:174)
+        self._inventory = build_parameters(self, config)
+        self.embedding_size = embedding_sizes(config.model)
+        self._n_timesteps = config.diffusion.num_diffusion_timesteps
+        dev, act = parse_tensor_type(getattr(config.model, "dtype", None))
+        tr_dtype = getattr(config.model.transformers, "dtype", None)
+        if tr_dtype:
+            parse_tensor_type(tr_dtype)  # validate; the FNet always computes in fp32 (reference :242-246,267-279)
+        self._act_dtype = act
+        self._handle = None
+        self._packed = None
+        self._packed_key = None
+        self._dirty = True
+        self._tables = {}
+        self._workspace = None
+        if dev == "cuda":
+            self.to("cuda")  # like nn.Module.type("torch.cuda.FloatTensor") in the reference (:234-235)
+
+    # -- lifecycle -----------------------------------------------------------------------------------
+    def train(self, mode=True):
+        self._dirty = True  # EMAHelper.ema()/checkpoint loads precede .eval()/.train() in the reference runner
+        return super().train(mode)
+
+    def invalidate(self):
+        """Force re-packing of the weights on the next forward (after out-of-band ``.data`` writes)."""
+        self._dirty = True
+
+    def _apply(self, fn, *a, **k):
+        self._dirty = True
+        self._tables = {}
+        self._workspace = None
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            try:
+                from . import _lib
+                _lib.load().ddimx_destroy(h)
+            except Exception:
+                pass
+
+    def _ensure_handle(self):
+        from . import _lib
+        if self._handle is not None:
+            return _lib.load()
+        lib = _lib.load()
+        m = self.config
+        cfg = _lib.DdimxConfig()
+        cfg.in_channels, cfg.f_size, cfg.n_levels = m.channels, m.f_size, len(m.ch)
+        if len(m.ch) > _lib.MAX_LEVELS:
+            raise NotImplementedError("more than 8 U-Net levels")
+        for i, (c, r, k) in enumerate(zip(m.ch, m.res, m.krn)):
+            cfg.ch[i], cfg.res[i], cfg.krn[i] = c, r, k
+        kw = m.transformers.kwargs
+        if getattr(m.transformers, "module", "FNetEncoder") != "FNetEncoder":
+            raise NotImplementedError("only transformers.module == FNetEncoder is implemented")
+        if getattr(kw, "hidden_act", "gelu_new") != "gelu_new":
+            raise NotImplementedError("only hidden_act == gelu_new is implemented")
+        cfg.n_timesteps = self._n_timesteps
+        cfg.fnet_hidden, cfg.fnet_layers, cfg.fnet_inter = kw.hidden_size, kw.num_hidden_layers, kw.intermediate_size
+        cfg.fnet_ln_eps = kw.layer_norm_eps
+        cfg.act_dtype = _lib.DDIMX_BF16 if self._act_dtype == torch.bfloat16 else _lib.DDIMX_F32
+        import ctypes
+        h = ctypes.c_void_p()
+        _lib.check(lib.ddimx_create(ctypes.byref(cfg), ctypes.byref(h)))
+        # cross-check the host mirror against the library's plan (names, sizes, order)
+        n = lib.ddimx_num_params(h)
+        names = list(self._inventory.keys())
+        if n != len(names):
+            raise RuntimeError(f"libddimx plan has {n} tensors, host mirror {len(names)}")
+        nm, ne = ctypes.c_char_p(), ctypes.c_longlong()
+        for i, (name, shape) in enumerate(self._inventory.items()):
+            _lib.check(lib.ddimx_param_info(h, i, ctypes.byref(nm), ctypes.byref(ne)))
+            numel = 1
+            for d in shape:
+                numel *= d
+            if nm.value.decode() != name or ne.value != numel:
+                raise RuntimeError(f"plan mismatch at {i}: {nm.value.decode()}[{ne.value}] vs {name}[{numel}]")
+        self._handle = h
+        return lib
+
+    def _state_tensors(self):
+        sd = dict(self.named_parameters())
+        sd["temb.te"] = self.temb.te
+        return [sd[k] for k in self._inventory]
+
+    def _ensure_packed(self, lib, device):
+        from . import _lib
+        tensors = self._state_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if not self._dirty and self._packed is not None and key == self._packed_key:
+            return
+        for name, t in zip(self._inventory, tensors):
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"parameter {name} must be a contiguous fp32 tensor on {device} (is {t.dtype} on {t.device})")
+        if self._packed is None or self._packed.device != device:
+            self._packed = torch.empty(int(lib.ddimx_packed_bytes(self._handle)), dtype=torch.uint8, device=device)
+        import ctypes
+        arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        _lib.check(lib.ddimx_pack_weights(self._handle, arr, len(tensors), _lib.ptr(self._packed), _lib.stream()))
+        self._packed_key = key
+        self._dirty = False
+
+    def _ensure_tables(self, t_len, device):
+        key = (t_len, str(device))
+        if key not in self._tables:
+            nlev = len(self.config.ch)
+            s = t_len >> (nlev - 1)
+            fr = self.config.f_size >> (nlev - 1)
+            c_last = self.config.ch[-1]
+            hid = self.config.transformers.kwargs.hidden_size
+            pe = _posenc_table(s, c_last * fr, c_last, fr).to(device)
+            ch, sh = _dft_tables(hid)
+            cs, ss = _dft_tables(s)
+            import numpy as np
+            dh = torch.from_numpy(np.concatenate([ch, sh], axis=0)).to(device)
+            ds = torch.from_numpy(np.stack([cs, -ss], axis=0)).to(device)
+            self._tables = {key: (pe, dh, ds)}  # keep only the latest T
+        return self._tables[key]
+
+    # -- forward -------------------------------------------------------------------------------------
+    def forward(self, input, t):
+        """input [B, C, T, F] fp32 on the GPU, t [B] int64 -> eps [B, C, T, F] fp32 (reference :237-294, eval)."""
+        from . import _lib
+        if not input.is_cuda:
+            raise RuntimeError("ddim_audio_amd.Model computes only through libddimx on a ROCm GPU; got a CPU tensor "
+                               "(there is no CPU fallback)")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training-mode forward/backward kernels (dropout, autograd) are not built yet; "
+                                      "call model.eval() or run under torch.no_grad()")
+        if input.dtype != torch.float32:
+            raise RuntimeError("the network boundary is fp32 [B,C,T,F] (activations inside use config.model.dtype)")
+        b, c, t_len, f = input.shape
+        if c != self.config.channels or f != self.config.f_size:
+            raise RuntimeError(f"expected [B,{self.config.channels},T,{self.config.f_size}], got {tuple(input.shape)}")
+        lib = self._ensure_handle()
+        dev = input.device
+        with torch.cuda.device(dev):
+            self._ensure_packed(lib, dev)
+            pe, dh, ds = self._ensure_tables(t_len, dev)
+            need = int(lib.ddimx_workspace_bytes(self._handle, b, t_len))
+            if need <= 0:
+                raise RuntimeError("libddimx: bad workspace size for B=%d T=%d" % (b, t_len))
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            x = input.contiguous()
+            tt = t.to(device=dev, dtype=torch.int64).contiguous()
+            out = torch.empty_like(x)
+            tables = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr())
+            import ctypes
+            _lib.check(lib.ddimx_unet_fwd(self._handle, _lib.ptr(self._packed), ctypes.byref(tables),
+                                          _lib.ptr(self._workspace), self._workspace.numel(), _lib.ptr(x), _lib.ptr(tt),
+                                          _lib.ptr(out), b, t_len, _lib.stream()))
+        return out

@@ -1,0 +1,143 @@
+/* libddimx -- C ABI of the MI355X-native DDIM denoising hot path (gfx950).
+ *
+ * The reference (klae01/ddim-audio) is pure Python and has no FFI of its own; its boundary for this
+ * path is the Python API  Model(config) / model(x, t) / generalized_steps(...)  (SURVEY.md section 8b).
+ * This header is the native interface introduced *underneath* that API: each entry point names the
+ * reference code whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; ddimx_last_error() gives the message;
+ *     nothing aborts or exits (the reference's main.py logs exceptions, main.py:212-223).
+ *   - all pointers except `ddimx_config*`, host pointer arrays and host scalars are DEVICE pointers
+ *     owned by the caller (PyTorch); the library borrows them for the duration of one call, never
+ *     allocates device memory, never synchronises: every call only enqueues work on `stream`
+ *     (a hipStream_t passed as void*), so call sequences can be captured into a hipGraph.
+ *   - activations inside the network are NHWC ([B][T'][F'][C], channels innermost) in the
+ *     activation dtype (DDIMX_F32 or DDIMX_BF16); the network boundary is the reference's
+ *     NCHW fp32 [B][C][T][F] (models/diffusion.py:238-240).
+ */
+#ifndef DDIMX_H
+#define DDIMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDIMX_ABI_VERSION 1
+#define DDIMX_MAX_LEVELS 8
+#define DDIMX_F32 0
+#define DDIMX_BF16 1
+
+/* config.model.* and config.diffusion.num_diffusion_timesteps as read by Model.__init__
+ * (models/diffusion.py:170-235; configs/audio.yml:25-61). */
+typedef struct {
+    int in_channels;                 /* model.channels (2) */
+    int f_size;                      /* model.f_size (256) */
+    int n_levels;                    /* len(model.ch) */
+    int ch[DDIMX_MAX_LEVELS];        /* model.ch */
+    int res[DDIMX_MAX_LEVELS];       /* model.res */
+    int krn[DDIMX_MAX_LEVELS];       /* model.krn (3 only) */
+    int n_timesteps;                 /* diffusion.num_diffusion_timesteps */
+    int fnet_hidden;                 /* transformers.kwargs.hidden_size */
+    int fnet_layers;                 /* transformers.kwargs.num_hidden_layers */
+    int fnet_inter;                  /* transformers.kwargs.intermediate_size */
+    float fnet_ln_eps;               /* transformers.kwargs.layer_norm_eps */
+    int act_dtype;                   /* DDIMX_F32 (parity mode) or DDIMX_BF16 */
+} ddimx_config;
+
+/* Host-built constant tables for a given T (device pointers, fp32):
+ *   posenc     [S][width]    Add_Encoding table (models/diffusion.py:81-92,131-140) in NHWC token order
+ *   dft_hidden [2*hid][hid]  rows 0..hid-1 = cos(2 pi k n / hid), rows hid.. = sin(...)
+ *   dft_seq    [2][S][S]     cos(2 pi k n / S) and -sin(2 pi k n / S)
+ * with S = T / 2^(n_levels-1), width = ch[-1] * f_size / 2^(n_levels-1). */
+typedef struct {
+    const float* posenc;
+    const float* dft_hidden;
+    const float* dft_seq;
+} ddimx_tables;
+
+typedef struct ddimx_ctx* ddimx_handle;
+
+int ddimx_abi_version(void);
+const char* ddimx_last_error(void);
+
+/* Model.__init__ (models/diffusion.py:170-235): validates the configuration, builds the packing and
+ * launch plan.  No device memory is allocated. */
+int ddimx_create(const ddimx_config* cfg, ddimx_handle* out);
+int ddimx_destroy(ddimx_handle h);
+
+/* Number of state_dict entries (388 parameters + temb.te = 389 for configs/audio.yml), in the
+ * reference's registration order; name/shape of entry i for cross-checking the host mirror. */
+int ddimx_num_params(ddimx_handle h);
+int ddimx_param_info(ddimx_handle h, int i, const char** name, long long* numel);
+
+/* Bytes of the packed-weight buffer / of the workspace for a [B,2,T,F] forward. */
+long long ddimx_packed_bytes(ddimx_handle h);
+long long ddimx_workspace_bytes(ddimx_handle h, int B, int T);
+
+/* Convert the fp32 parameters (device pointers, state_dict order) to the internal layouts
+ * (implicit-GEMM conv weights in the activation dtype, sub-pixel ConvTranspose weights, FNet boundary
+ * in NHWC token order).  Must be re-run whenever parameters change (optimizer step, load_state_dict,
+ * EMAHelper.ema: models/ema.py:25-30). */
+int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, void* packed, void* stream);
+
+/* Model.forward (models/diffusion.py:237-294), eval mode: x [B][C][T][F] fp32, t [B] int64 -> eps. */
+int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace,
+                   long long workspace_bytes, const float* x, const int64_t* t, float* eps, int B, int T,
+                   void* stream);
+
+/* ---- per-op entry points (same kernels as ddimx_unet_fwd; used by the parity tests) ------------- */
+/* layout helpers: NCHW fp32 <-> NHWC activation dtype */
+int ddimx_to_nhwc(int dtype, const float* nchw, void* nhwc, int B, int C, int H, int W, void* stream);
+int ddimx_from_nhwc(int dtype, const void* nhwc, float* nchw, int B, int C, int H, int W, void* stream);
+/* weight packing of single layers: Conv2d [O][I][KH][KW] -> [KH*KW][O][I]; ConvTranspose2d(k4,s2,p1)
+ * [I][O][4][4] -> [2][6][2*O][I] (sub-pixel form, see csrc/kernels.hip) */
+int ddimx_pack_conv(int dtype, const float* w, void* dst, int O, int I, int KH, int KW, void* stream);
+int ddimx_pack_convT(int dtype, const float* w, void* dst, int I, int O, void* stream);
+long long ddimx_op_workspace_bytes(int dtype, int B, int C, int H, int W);
+
+/* Residual_Block.forward (models/diffusion.py:42-56) on NHWC x -> y (may alias x).  gn*_ are fp32
+ * [C]; w0/w1 packed by ddimx_pack_conv; temb [B][temb_stride] fp32 (already offset to this block). */
+int ddimx_resblock_fwd(int dtype, int C, const void* x, void* y, const float* temb, int temb_stride,
+                       const float* gn0_w, const float* gn0_b, const void* w0, const float* gn1_w,
+                       const float* gn1_b, const void* w1, const float* bias1, const float* gn2_w, void* workspace,
+                       int B, int H, int W, void* stream);
+/* Downsample.forward (models/diffusion.py:70-78): [B][H][W][Cin] -> [B][H/2][W/2][Cout] */
+int ddimx_downsample_fwd(int dtype, int Cin, int Cout, const void* x, const void* w, const float* bias, void* y,
+                         int B, int H, int W, void* stream);
+/* Upsample.forward + the skip add that follows it (models/diffusion.py:59-67,284):
+ * [B][H][W][Cin] -> [B][2H][2W][Cout] + skip.  bias2 is the bias repeated twice ([2*Cout]). */
+int ddimx_upsample_add_fwd(int dtype, int Cin, int Cout, const void* x, const void* w, const float* bias2,
+                           const void* skip, void* y, int B, int H, int W, void* stream);
+/* BetaEmbedding.forward (models/diffusion.py:110-120): t [B] -> out [B][E]; h1/h2 [B][512] scratch */
+int ddimx_temb_fwd(const float* te, const int64_t* t, const float* w0, const float* b0, const float* w1,
+                   const float* b1, const float* w2, const float* b2, float* h1, float* h2, float* out, int B,
+                   int pos_ch, int emb_ch, int E, void* stream);
+
+/* ---- sampler (functions/denoising.py:10-52) ------------------------------------------------------- */
+/* coef [n_iter][6] fp32 rows (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1); step: device int counter.
+ * step_begin fills t[B] with the current timestep; ddim_update performs lines :27 and :41-43 in one pass,
+ * writing the x0 prediction to x0 and x_{t-1} in place; step_end advances the counter. */
+int ddimx_step_begin(const float* coef, const int* step, int64_t* t, int B, void* stream);
+int ddimx_ddim_update(float* xt, const float* et, const float* noise, float* x0, const float* coef, const int* step,
+                      long long n, void* stream);
+int ddimx_step_end(int* step, void* stream);
+
+/* ---- training-step pieces (functions/losses.py:4-18, models/ema.py:16-23) ---------------------------- */
+int ddimx_qsample(const float* x0, const float* e, const float* alphas, const int64_t* t, float* x, int B,
+                  long long per_sample, void* stream);
+/* loss[0..B-1] = per-sample sum of squared error, loss[B] = batch mean; partial: [B*64] scratch */
+int ddimx_sqerr_loss(const float* e, const float* out, float* partial, float* loss, int B, long long per_sample,
+                     void* stream);
+int ddimx_ema_block_elems(void);
+/* shadow = (1-mu)*param + mu*shadow for a list of tensors in one launch (pointer tables on device) */
+int ddimx_ema_update_multi(const long long* shadow_ptrs, const long long* param_ptrs, const long long* sizes,
+                           const int* blk_tensor, const long long* blk_off, int nblocks, float mu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDIMX_H */
