@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Benchmark of the DDIM denoising hot path (BASELINE.json metric:
+"DDIM denoising steps/sec (U-Net fwd/s), 1000-step sample, spectrogram batch").
+
+A *step* is one iteration of ``generalized_steps`` over one batch: timestep fill, U-Net forward
+(``Model.forward``), fused x0-prediction + x_{t-1} update -- exactly the product path
+(``ddim_audio_amd.sampler.DDIMStepper``, hipGraph replay of libddimx launches).
+Workload at N=1 = BASELINE.json configs[1]: batch 8 spectrograms [8,2,1024,256], audio.yml U-Net
+(47.2 M parameters, deterministic synthetic weights), 1000-step eta=0 schedule, bf16 activations.
+``value`` = sample-forwards per second over all ranks = N * B * K / t  (one unit = one spectrogram
+through one U-Net evaluation + one DDIM update); iterations/s is reported beside it.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the contract in the task statement) with two extra objects:
+``roofline`` (dominant kernel, algorithmic bytes / measured launch time vs the HBM peak) and
+``cpu_baseline`` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def per_kernel_times(model, B, T, reps=20):
+    """Time the hot kernels one by one with HIP events on the launch stream (torch's current stream is
+    the stream libddimx launches on).  Returns a list of dicts, one per kernel family and level."""
+    from ddim_audio_amd import _lib
+    lib = _lib.load()
+    m = model.config
+    bf16 = model._act_dtype == torch.bfloat16
+    dt = _lib.DDIMX_BF16 if bf16 else _lib.DDIMX_F32
+    tdt = torch.bfloat16 if bf16 else torch.float32
+    es = 2 if bf16 else 4
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rows = []
+
+    def timed(fn):
+        fn(); fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3  # seconds per launch
+
+    for lvl, (C, res) in enumerate(zip(m.ch, m.res)):
+        H, W = T >> lvl, m.f_size >> lvl
+        x = torch.randn(B, H, W, C, device=dev).to(tdt)
+        y = torch.empty_like(x)
+        h = torch.randn(B, H, W, C, device=dev).to(tdt)
+        w = (torch.randn(9 * C * C, device=dev) * (1.0 / (9 * C) ** 0.5)).to(tdt)
+        bias = torch.randn(C, device=dev) * 0.1
+        temb = torch.randn(B, C, device=dev) * 0.1
+        scale = torch.rand(B, C, device=dev) + 0.5
+        shift = torch.randn(B, C, device=dev) * 0.1
+        stats = torch.empty(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)) + 2 * B * C * 4096, device=dev)
+        st = _lib.stream()
+
+        def conv():
+            _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale),
+                                             _lib.ptr(shift), 2, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+
+        def resid():
+            _lib.check(lib.ddimx_resid_gn_fwd(dt, C, _lib.ptr(x), _lib.ptr(h), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
+                                              _lib.ptr(stats), B, H, W, st))
+
+        elems = B * H * W * C
+        tc, tr = timed(conv), timed(resid)
+        rows.append(dict(kernel=f"conv_mfma_kernel<{'bf16' if bf16 else 'f32'},C={C},3x3>", level=lvl, launches_per_fwd=4 * res,
+                         seconds=tc, alg_bytes=2 * elems * es + 9 * C * C * es, flops=2.0 * elems * 9 * C))
+        rows.append(dict(kernel=f"resid_kernel<{'bf16' if bf16 else 'f32'},C={C}>", level=lvl, launches_per_fwd=2 * res,
+                         seconds=tr, alg_bytes=3 * elems * es, flops=3.0 * elems))
+        del x, y, h, stats
+    return rows
+
+
+def cpu_baseline(T, iters=3, batch=2):
+    """The CPU oracle (plain PyTorch fp32 restatement, pinned to the reference by golden vectors) on the
+    host cores: ``iters`` DDIM iterations at batch ``batch`` after one small warm-up."""
+    from ddim_audio_amd import configs, schedule, synth
+    from ddim_audio_amd.model import state_inventory
+    from oracle import ref_cpu
+    cfg = configs.audio_config("torch.FloatTensor")
+    sd = {k: torch.empty(s) for k, s in state_inventory(cfg).items()}
+    synth.fill_state_dict(sd)
+    sd["temb.te"] = ref_cpu.timestep_table(cfg.diffusion.num_diffusion_timesteps)
+    alphas = schedule.make_schedule(cfg.diffusion)[1]
+    cores = torch.get_num_threads()
+    fn = lambda a, b: ref_cpu.model_forward(sd, cfg, a, b)  # noqa: E731
+    with torch.no_grad():
+        ref_cpu.model_forward(sd, cfg, torch.randn(1, 2, 64, 256), torch.tensor([10]))  # warm-up
+        x = torch.randn(batch, 2, T, 256)
+        seq = [int(v) for v in torch.linspace(0, 999, iters).tolist()]
+        t0 = time.perf_counter()
+        ref_cpu.generalized_steps(x, seq, fn, alphas, [-1], eta=0.0)
+        dt = time.perf_counter() - t0
+    return dict(value=batch * iters / dt, unit="sample-fwd/s", cores=cores, kind="port",
+                sample=f"{iters} DDIM iterations x batch {batch} at T={T} (oracle/ref_cpu.py, fp32, {cores} threads), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="spectrograms per GPU (weak scaling)")
+    ap.add_argument("--t-size", type=int, default=1024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import numpy as np
+    import ddim_audio_amd as D
+    from ddim_audio_amd import configs, schedule, synth
+    from ddim_audio_amd.sampler import DDIMStepper
+
+    B, T = args.batch, args.t_size
+    tstr = "torch.cuda.BFloat16Tensor" if args.dtype == "bf16" else "torch.cuda.FloatTensor"
+    cfg = configs.audio_config(tstr)
+    model = synth.fill_module(D.Model(cfg)).eval()
+    alphas = schedule.make_schedule(cfg.diffusion)[1]
+    n_sched = cfg.diffusion.num_diffusion_timesteps
+    coef = schedule.ddim_coefficients(schedule.make_seq(n_sched, n_sched), alphas, 0.0)  # the 1000-step sample
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x = torch.randn(B, 2, T, cfg.model.f_size, device=dev, generator=g)
+
+    with torch.no_grad():
+        stepper = DDIMStepper(model, x, coef)
+
+        def run(n):
+            for _ in range(n):
+                if stepper.done and stepper.done % n_sched == 0:  # schedule exhausted: restart from fresh noise
+                    stepper.rewind()
+                    x.normal_(generator=g)
+                stepper.step()
+
+        run(max(args.warmup, 2))  # >= 2: step 0 is eager and sizes the workspace, step 1 replays the captured graph
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+    elapsed = float(et.item())
+    finite = bool(torch.isfinite(x).all().item())
+
+    if rank == 0:
+        iters_per_s = args.steps / elapsed
+        out = {
+            "metric": "DDIM denoising steps/sec (U-Net fwd/s), 1000-step sample, spectrogram batch",
+            "value": world * B * iters_per_s,
+            "unit": "sample-fwd/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: batch {B}/GPU x [2,{T},256] spectrograms, audio.yml U-Net (47.2M params, "
+                                   f"hash-filled weights), generalized_steps eta=0 over the 1000-step schedule, hipGraph replay",
+                       "global_batch": world * B, "t_size": T, "parallelism": f"batch-sharded x{world}, no collective in the loop"},
+            "iters_per_s": iters_per_s,
+            "output_finite": finite,
+        }
+        flops = 159.22e9 * T / 1024.0  # algorithmic FLOPs per sample-forward
+        out["model_tflops"] = out["value"] * flops / 1e12
+        if not args.no_roofline:
+            with torch.no_grad():
+                rows = per_kernel_times(model, B, T)
+            for r in rows:
+                r["gbps"] = r["alg_bytes"] / r["seconds"] / 1e9
+                r["tflops"] = r["flops"] / r["seconds"] / 1e12
+                r["ms_per_fwd"] = r["seconds"] * r["launches_per_fwd"] * 1e3
+            dom = max(rows, key=lambda r: r["ms_per_fwd"])
+            ai = dom["flops"] / dom["alg_bytes"]
+            bound = "hbm" if ai < MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"
+            if bound == "hbm":
+                out["roofline"] = {"bound": "hbm", "achieved": dom["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": dom["gbps"] / HBM_PEAK_GBS, "traffic": None}
+            else:
+                out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": dom["tflops"] / MFMA_BF16_PEAK_TF, "traffic": None}
+            out["roofline"].update(kernel=dom["kernel"], launch_us=dom["seconds"] * 1e6, alg_bytes_per_launch=dom["alg_bytes"],
+                                   launches_per_fwd=dom["launches_per_fwd"])
+            out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

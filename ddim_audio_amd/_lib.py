@@ -43,6 +43,11 @@ _SIGS = {
     "ddimx_op_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "ddimx_resblock_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 8 +
                            [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddimx_conv3x3_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddimx_conv3x3_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
+    "ddimx_resid_gn_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_void_p]),
     "ddimx_downsample_fwd": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p]),
     "ddimx_upsample_add_fwd": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -605,6 +605,20 @@ int ddimx_resblock_fwd(int dtype, int C, const void* x, void* y, const float* te
     return run_resblock(dtype, C, x, y, temb, temb_stride, p, o.h1, o.h2, o.stats, o.scale, o.shift,
                         resid_nparts(dtype, H * W, C), C, false, nullptr, B, H, W, s);
 }
+int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const float* bias, const float* chan_add,
+                      int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
+                      float* stats, int B, int H, int W, void* stream) {
+    ConvCall k = {dtype, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
+    return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
+}
+long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W) {
+    return (long long)conv_stats_floats(dtype, CONV3, C, C, B, H, W);
+}
+int ddimx_resid_gn_fwd(int dtype, int C, const void* x, const void* h, const float* scale, const float* shift, void* y,
+                       float* stats, int B, int H, int W, void* stream) {
+    HIPCHK(resid_launch(dtype, x, h, 0, scale, shift, y, stats, B, H * W, C, (hipStream_t)stream));
+    return 0;
+}
 int ddimx_downsample_fwd(int dtype, int Cin, int Cout, const void* x, const void* w, const float* bias, void* y, int B,
                          int H, int W, void* stream) {
     ConvCall d = {dtype, DOWN4, Cin, Cout, x, w, bias, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, y, nullptr, B, H, W};

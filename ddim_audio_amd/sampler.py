@@ -21,23 +21,57 @@ def _selected(select_index, index, n):
     return select_index is None or index in select_index or index - n in select_index
 
 
-class _StepState:
-    """Device-side state of one sampling run: coefficient table, step counter, timestep vector."""
+class DDIMStepper:
+    """One sampling run's device state and its step function.
 
-    def __init__(self, coef64, batch, device):
-        self.coef = torch.from_numpy(coef64.astype(np.float32)).to(device).contiguous()
-        self.step = torch.zeros(1, dtype=torch.int32, device=device)
-        self.t = torch.zeros(batch, dtype=torch.int64, device=device)
+    ``step()`` = reference ``functions/denoising.py:22-43`` for one iteration: timestep fill, model
+    forward, fused x0-prediction + x_{t-1} update, counter advance.  The scalars come from a device
+    table indexed by a device counter, so after the first (eager) step the same launch sequence is
+    captured once into a hipGraph and replayed for every later step.
+    """
 
+    def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None):
+        self.lib = _lib.load()
+        self.model, self.xt = model, xt
+        dev = xt.device
+        self.coef = torch.from_numpy(np.ascontiguousarray(coef64, dtype=np.float32)).to(dev).contiguous()
+        self.n_iter = self.coef.size(0)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.t = torch.zeros(xt.size(0), dtype=torch.int64, device=dev)
+        self.x0 = torch.empty_like(xt)
+        self.noise_fn = noise_fn
+        self.use_graph = (use_graph and noise_fn is None and os.environ.get("DDIMX_GRAPH", "1") != "0"
+                          and not torch.cuda.is_current_stream_capturing())
+        self.graph = None
+        self.done = 0
 
-def _one_step(lib, model, xt, x0buf, st, noise):
-    _lib.check(lib.ddimx_step_begin(_lib.ptr(st.coef), _lib.ptr(st.step), _lib.ptr(st.t), st.t.numel(), _lib.stream()))
-    et = model(xt, st.t)
-    if et.dtype != torch.float32 or not et.is_contiguous():
-        et = et.float().contiguous()
-    _lib.check(lib.ddimx_ddim_update(_lib.ptr(xt), _lib.ptr(et), _lib.ptr(noise), _lib.ptr(x0buf), _lib.ptr(st.coef),
-                                     _lib.ptr(st.step), xt.numel(), _lib.stream()))
-    _lib.check(lib.ddimx_step_end(_lib.ptr(st.step), _lib.stream()))
+    def _launch(self, noise):
+        lib, st = self.lib, _lib.stream()
+        _lib.check(lib.ddimx_step_begin(_lib.ptr(self.coef), _lib.ptr(self.counter), _lib.ptr(self.t), self.t.numel(), st))
+        et = self.model(self.xt, self.t)
+        if et.dtype != torch.float32 or not et.is_contiguous():
+            et = et.float().contiguous()
+        _lib.check(lib.ddimx_ddim_update(_lib.ptr(self.xt), _lib.ptr(et), _lib.ptr(noise), _lib.ptr(self.x0), _lib.ptr(self.coef),
+                                         _lib.ptr(self.counter), self.xt.numel(), st))
+        _lib.check(lib.ddimx_step_end(_lib.ptr(self.counter), st))
+
+    def rewind(self):
+        """Restart the coefficient table (benchmark loops longer than the schedule)."""
+        self.counter.zero_()
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch(self.noise_fn(self.xt) if self.noise_fn is not None else None)
+            if self.use_graph and self.done == 0:
+                # step 0 ran eagerly (it also sized the model's workspace); capture one generic step
+                torch.cuda.synchronize(self.xt.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch(None)
+                self.graph = g
+        self.done += 1
 
 
 def generalized_steps(x, seq, model, alpha, select_index, **kwargs):
@@ -63,29 +97,11 @@ def generalized_steps(x, seq, model, alpha, select_index, **kwargs):
         if xt.numel() % 4:
             raise RuntimeError("sample tensor size must be a multiple of 4 elements")
         coef = ddim_coefficients(seq, alpha, eta)
-        st = _StepState(coef, xt.size(0), device)
-        x0buf = torch.empty_like(xt)
-        use_graph = (eta == 0.0 and n_iter >= 4 and os.environ.get("DDIMX_GRAPH", "1") != "0"
-                     and not torch.cuda.is_current_stream_capturing())
-        graph = None
+        noise_fn = (lambda ref: torch.randn_like(ref)) if eta != 0.0 else None  # reference :42 draws it every step
+        stepper = DDIMStepper(model, xt, coef, use_graph=(n_iter >= 4), noise_fn=noise_fn)
         for index in range(n_iter):
-            noise = torch.randn_like(xt) if eta != 0.0 else None
-            if graph is not None:
-                graph.replay()
-            else:
-                _one_step(lib, model, xt, x0buf, st, noise)
-                if use_graph and index == 0:
-                    # step 0 ran eagerly (it also sized the model's workspace); capture one generic step
-                    torch.cuda.synchronize(device)
-                    graph = torch.cuda.CUDAGraph()
-                    try:
-                        with torch.cuda.graph(graph):
-                            _one_step(lib, model, xt, x0buf, st, None)
-                    except Exception:
-                        graph = None
-                        use_graph = False
-                        raise
+            stepper.step()
             if _selected(select_index, index, n_iter):
-                x0_preds.append(x0buf.to("cpu"))
+                x0_preds.append(stepper.x0.to("cpu"))
                 xs.append(xt.to("cpu"))
     return xs, x0_preds

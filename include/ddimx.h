@@ -105,6 +105,18 @@ int ddimx_resblock_fwd(int dtype, int C, const void* x, void* y, const float* te
                        const float* gn0_w, const float* gn0_b, const void* w0, const float* gn1_w,
                        const float* gn1_b, const void* w1, const float* bias1, const float* gn2_w, void* workspace,
                        int B, int H, int W, void* stream);
+/* One fused 3x3 convolution of a Residual_Block (models/diffusion.py:28-40,46-53): the GroupNorm
+ * affine (xf = 1) or affine + SiLU (xf = 2) folded as per-(sample, channel) scale/shift [B][C] is applied
+ * to the input while it is staged; epilogue adds bias [C] and chan_add [B][chan_add_stride] (either may
+ * be null), applies SiLU when act = 1, and writes per-channel (sum, sumsq) partials to stats (nullable;
+ * ddimx_conv3x3_stats_floats() floats).  x, y: NHWC [B][H][W][C]. */
+int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const float* bias, const float* chan_add,
+                      int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
+                      float* stats, int B, int H, int W, void* stream);
+long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W);
+/* y = x + (h * scale + shift): tail of Residual_Block (models/diffusion.py:54-56), NHWC, stats nullable */
+int ddimx_resid_gn_fwd(int dtype, int C, const void* x, const void* h, const float* scale, const float* shift, void* y,
+                       float* stats, int B, int H, int W, void* stream);
 /* Downsample.forward (models/diffusion.py:70-78): [B][H][W][Cin] -> [B][H/2][W/2][Cout] */
 int ddimx_downsample_fwd(int dtype, int Cin, int Cout, const void* x, const void* w, const float* bias, void* y,
                          int B, int H, int W, void* stream);
