@@ -5,7 +5,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddimx.so")
+LIB_PATH = os.environ.get("DDIMX_LIB", os.path.join(_HERE, "libddimx.so"))
 
 DDIMX_F32, DDIMX_BF16 = 0, 1
 MAX_LEVELS = 8
@@ -46,6 +46,7 @@ _SIGS = {
     "ddimx_conv3x3_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddimx_conv3x3_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
+    "ddimx_debug_conv3x3_stamps": (c_int, [c_int, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "ddimx_resid_gn_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_void_p]),
     "ddimx_downsample_fwd": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

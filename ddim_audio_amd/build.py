@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libddimx.so")
 ORACLE_DIR = os.path.join(os.path.dirname(HERE), "oracle")
-SOURCES = ["api.cpp", "kernels.hip", "gemm_f32.hip", "conv_inst_bf16_c3.hip", "conv_inst_bf16_du.hip",
+SOURCES = ["api.cpp", "kernels.hip", "gemm.hip", "conv_inst_bf16_c3.hip", "conv_inst_bf16_du.hip",
            "conv_inst_f32_c3.hip", "conv_inst_f32_du.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
 
@@ -25,9 +25,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, jobs=None):
+def build(force=False, verbose=True, jobs=None, stamp=False):
+    """stamp=True builds the diagnostic variant libddimx_stamp.so (-DDDIMX_STAMP: in-kernel phase timers)."""
+    global OUT, FLAGS
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    bdir = os.path.join(CSRC, "build")
+    bdir = os.path.join(CSRC, "build_stamp" if stamp else "build")
+    if stamp:
+        OUT = os.path.join(HERE, "libddimx_stamp.so")
+        FLAGS = FLAGS + ["-DDDIMX_STAMP"]
     os.makedirs(bdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "ddimx.h"))
@@ -63,4 +68,4 @@ def build(force=False, verbose=True, jobs=None):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, stamp="--stamp" in sys.argv)

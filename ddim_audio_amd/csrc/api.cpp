@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -13,26 +14,37 @@
 #include "kernels.h"
 
 namespace ddimx {
-hipError_t conv_geometry_bf16_c3(int, int, int, ConvGeom*);
-hipError_t conv_geometry_bf16_du(int, int, int, ConvGeom*);
-hipError_t conv_geometry_f32_c3(int, int, int, ConvGeom*);
-hipError_t conv_geometry_f32_du(int, int, int, ConvGeom*);
-hipError_t conv_launch_bf16_c3(int, int, int, ConvArgs&, hipStream_t);
-hipError_t conv_launch_bf16_du(int, int, int, ConvArgs&, hipStream_t);
-hipError_t conv_launch_f32_c3(int, int, int, ConvArgs&, hipStream_t);
-hipError_t conv_launch_f32_du(int, int, int, ConvArgs&, hipStream_t);
+hipError_t conv_geometry_bf16_c3(int, int, int, int, ConvGeom*);
+hipError_t conv_geometry_bf16_du(int, int, int, int, ConvGeom*);
+hipError_t conv_geometry_f32_c3(int, int, int, int, ConvGeom*);
+hipError_t conv_geometry_f32_du(int, int, int, int, ConvGeom*);
+hipError_t conv_launch_bf16_c3(int, int, int, int, ConvArgs&, hipStream_t);
+hipError_t conv_launch_bf16_du(int, int, int, int, ConvArgs&, hipStream_t);
+hipError_t conv_launch_f32_c3(int, int, int, int, ConvArgs&, hipStream_t);
+hipError_t conv_launch_f32_du(int, int, int, int, ConvArgs&, hipStream_t);
 
-hipError_t conv_geometry(int dtype, int mode, int cin, int cout, ConvGeom* g) {
+hipError_t conv_geometry(int dtype, int mode, int cin, int cout, int var, ConvGeom* g) {
     const int nout = mode == UP4 ? 2 * cout : cout;
     if (dtype == DT_BF16)
-        return mode == CONV3 ? conv_geometry_bf16_c3(mode, cin, nout, g) : conv_geometry_bf16_du(mode, cin, nout, g);
-    return mode == CONV3 ? conv_geometry_f32_c3(mode, cin, nout, g) : conv_geometry_f32_du(mode, cin, nout, g);
+        return mode == CONV3 ? conv_geometry_bf16_c3(mode, cin, nout, var, g) : conv_geometry_bf16_du(mode, cin, nout, var, g);
+    return mode == CONV3 ? conv_geometry_f32_c3(mode, cin, nout, var, g) : conv_geometry_f32_du(mode, cin, nout, var, g);
 }
-hipError_t conv_launch(int dtype, int mode, int cin, int cout, ConvArgs& a, hipStream_t s) {
+hipError_t conv_launch(int dtype, int mode, int cin, int cout, int var, ConvArgs& a, hipStream_t s) {
     const int nout = mode == UP4 ? 2 * cout : cout;
     if (dtype == DT_BF16)
-        return mode == CONV3 ? conv_launch_bf16_c3(mode, cin, nout, a, s) : conv_launch_bf16_du(mode, cin, nout, a, s);
-    return mode == CONV3 ? conv_launch_f32_c3(mode, cin, nout, a, s) : conv_launch_f32_du(mode, cin, nout, a, s);
+        return mode == CONV3 ? conv_launch_bf16_c3(mode, cin, nout, var, a, s) : conv_launch_bf16_du(mode, cin, nout, var, a, s);
+    return mode == CONV3 ? conv_launch_f32_c3(mode, cin, nout, var, a, s) : conv_launch_f32_du(mode, cin, nout, var, a, s);
+}
+int conv_pick_variant(int dtype, int mode, int cin, int cout, int B, int Hv, int Wv) {
+    ConvGeom g0, g1;
+    if (const char* e = getenv("DDIMX_CONV_VAR")) {  // tuning hook: force a candidate variant where one exists
+        const int v = atoi(e);
+        if (v >= 0 && conv_geometry(dtype, mode, cin, cout, v, &g0) == hipSuccess) return v;
+    }
+    if (conv_geometry(dtype, mode, cin, cout, 0, &g0) != hipSuccess) return 0;
+    if (conv_geometry(dtype, mode, cin, cout, 1, &g1) != hipSuccess) return 0;
+    const long long wgs0 = (long long)B * ((Wv + g0.tw - 1) / g0.tw) * ((Hv + g0.th - 1) / g0.th) * g0.classes * (g0.nout / g0.nb);
+    return wgs0 < 200 ? 1 : 0;  // measured on MI355X: the large tile wins from ~256 workgroups up (one per CU)
 }
 }  // namespace ddimx
 
@@ -63,7 +75,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t esz(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
 
 // ------------------------------------------------------------------------------------------ plan
-enum PackKind { PK_COPY, PK_CONV, PK_CONVT, PK_BIAS2, PK_PERM_COLS, PK_PERM_ROWS };
+enum PackKind { PK_COPY, PK_CONV, PK_CONVT, PK_BIAS2, PK_PERM_COLS, PK_PERM_ROWS, PK_CONV_F32 };
 
 struct ParamSpec {
     std::string name;
@@ -140,12 +152,12 @@ static int build_plan(ddimx_ctx* c) {
         if (f.krn[l] != 3) return fail("kernel size %d at level %d: only 3 is implemented", f.krn[l], l);
         if (f.ch[l] % 32) return fail("channel width %d at level %d must be a multiple of 32", f.ch[l], l);
         ConvGeom g;
-        if (conv_geometry(c->dtype, CONV3, f.ch[l], f.ch[l], &g) != hipSuccess)
+        if (conv_geometry(c->dtype, CONV3, f.ch[l], f.ch[l], 0, &g) != hipSuccess)
             return fail("no 3x3 conv kernel instantiated for %d channels", f.ch[l]);
         if (l > 0) {
-            if (conv_geometry(c->dtype, DOWN4, f.ch[l - 1], f.ch[l], &g) != hipSuccess)
+            if (conv_geometry(c->dtype, DOWN4, f.ch[l - 1], f.ch[l], 0, &g) != hipSuccess)
                 return fail("no downsample kernel instantiated for %d->%d", f.ch[l - 1], f.ch[l]);
-            if (conv_geometry(c->dtype, UP4, f.ch[l], f.ch[l - 1], &g) != hipSuccess)
+            if (conv_geometry(c->dtype, UP4, f.ch[l], f.ch[l - 1], 0, &g) != hipSuccess)
                 return fail("no upsample kernel instantiated for %d->%d", f.ch[l], f.ch[l - 1]);
         }
     }
@@ -187,7 +199,7 @@ static int build_plan(ddimx_ctx* c) {
             c->up_b[l] = add_spec(c, base + std::to_string(f.res[l]) + ".conv.bias", PK_BIAS2, f.ch[l - 1]);
         }
     }
-    c->out_w = add_spec(c, "up_modules." + std::to_string(L) + ".weight", PK_COPY, f.in_channels, f.ch[0], 3, 3);
+    c->out_w = add_spec(c, "up_modules." + std::to_string(L) + ".weight", PK_CONV_F32, f.in_channels, f.ch[0], 3, 3);
     c->out_b = add_spec(c, "up_modules." + std::to_string(L) + ".bias", PK_COPY, f.in_channels);
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width;
     c->ln0_w = add_spec(c, "transformer.embedding.LayerNorm.weight", PK_PERM_COLS, 1, width);
@@ -235,14 +247,19 @@ struct Ws {
     std::vector<void*> xd, xu;
     void *h1, *h2;
     float *stats, *scale, *shift;
-    float *ln0, *X, *Ut, *Z, *Y, *Hb, *O;
+    float *ln0, *X, *Ut, *Z, *Y, *Hb, *O, *gpart;
     size_t total;
 };
 
 static size_t conv_stats_floats(int dtype, int mode, int cin, int cout, int B, int Hv, int Wv) {
-    ConvGeom g;
-    if (conv_geometry(dtype, mode, cin, cout, &g) != hipSuccess) return 0;
-    return (size_t)B * cdiv(Wv, g.tw) * cdiv(Hv, g.th) * g.classes * g.nout * 2;
+    size_t mx = 0;
+    for (int var = 0; var < 8; ++var) {
+        ConvGeom g;
+        if (conv_geometry(dtype, mode, cin, cout, var, &g) != hipSuccess) continue;
+        const size_t n = (size_t)B * cdiv(Wv, g.tw) * cdiv(Hv, g.th) * g.classes * g.nout * 2;
+        if (n > mx) mx = n;
+    }
+    return mx;
 }
 
 static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
@@ -292,6 +309,17 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
     w->Y = (float*)cv.take(M * hid * 4);
     w->Hb = (float*)cv.take(M * inter * 4);
     w->O = (float*)cv.take(M * c->width * 4);
+    {   // split-K partial tiles of the skinny FNet GEMMs
+        const int bf = c->dtype == DT_BF16;
+        const int shp[6][5] = {{(int)M, hid, c->width, 1, bf}, {2 * hid, S, hid, B, 0}, {S, hid, S, B, 0},
+                               {(int)M, inter, hid, 1, bf}, {(int)M, hid, inter, 1, bf}, {(int)M, c->width, hid, 1, bf}};
+        size_t mx = 0;
+        for (auto& q : shp) {
+            const size_t n = (size_t)gemm_pick_splitk(q[0], q[1], q[2], q[3], q[4]) * q[3] * q[0] * q[1];
+            if (n > mx) mx = n;
+        }
+        w->gpart = (float*)cv.take(mx * 4);
+    }
     w->total = cv.off;
 }
 
@@ -302,12 +330,15 @@ struct ConvCall {
     const float* in_scale; const float* in_shift; int xf; int act;
     const void* skip; void* out; float* stats;
     int B, Hin, Win;
+    unsigned long long* stamps = nullptr;
 };
 
 // launches one fused conv; returns the stats slab geometry (nparts, Cs) it produced
 static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     ConvGeom g;
-    if (conv_geometry(q.dtype, q.mode, q.cin, q.cout, &g) != hipSuccess)
+    const int hv = q.mode == DOWN4 ? q.Hin / 2 : q.Hin, wv = q.mode == DOWN4 ? q.Win / 2 : q.Win;
+    const int var = conv_pick_variant(q.dtype, q.mode, q.cin, q.cout, q.B, hv, wv);
+    if (conv_geometry(q.dtype, q.mode, q.cin, q.cout, var, &g) != hipSuccess)
         return fail("conv %d->%d mode %d dtype %d: no kernel", q.cin, q.cout, q.mode, q.dtype);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -315,6 +346,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     a.in_scale = q.in_scale; a.in_shift = q.in_shift; a.xf = q.xf; a.act = q.act;
     a.skip = q.skip; a.out = q.out; a.stats = q.stats;
     a.B = q.B; a.Hin = q.Hin; a.Win = q.Win;
+    a.stamps = q.stamps;
     if (q.mode == DOWN4) {
         if ((q.Hin | q.Win) & 1) return fail("downsample needs even H, W (got %d x %d)", q.Hin, q.Win);
         a.Hv = q.Hin / 2; a.Wv = q.Win / 2;
@@ -323,9 +355,18 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     }
     a.tiles_x = cdiv(a.Wv, g.tw);
     a.tiles_y = cdiv(a.Hv, g.th);
-    if (nparts) *nparts = a.tiles_x * a.tiles_y * g.classes;
+    {   // persistent workgroups: each walks tiles_per_wg consecutive tiles of ONE sample.  The split depends only
+        // on the sample's size, never on the batch, so a sample's statistics partials (and hence its result, bit
+        // for bit) are the same alone, inside any batch, or on any number of GPUs.
+        const int tiles_s = a.tiles_x * a.tiles_y;
+        int wps = tiles_s < 128 ? tiles_s : 128;
+        if (const char* e = getenv("DDIMX_CONV_WPS")) { const int v = atoi(e); if (v > 0) wps = v < tiles_s ? v : tiles_s; }
+        a.tiles_per_wg = cdiv(tiles_s, wps);
+        a.wgs_per_sample = cdiv(tiles_s, a.tiles_per_wg);
+    }
+    if (nparts) *nparts = a.wgs_per_sample * g.classes;
     if (Cs) *Cs = g.nout;
-    HIPCHK(conv_launch(q.dtype, q.mode, q.cin, q.cout, a, s));
+    HIPCHK(conv_launch(q.dtype, q.mode, q.cin, q.cout, var, a, s));
     return 0;
 }
 
@@ -381,52 +422,50 @@ static int run_temb(const float* te, const int64_t* t, const float* w0, const fl
 
 // Transformer_Module (models/diffusion.py:131-167 + transformers modeling_fnet.py:138-279), eval mode.
 // x: NHWC bottleneck activation viewed as tokens [B*S][width]; writes O [B*S][width] fp32.
+// Dense-weight GEMMs use bf16 MFMA in bf16 mode; the DFT factors always run on the exact fp32 MFMA.
+static int fnet_gemm(const Ws& w, hipStream_t s, const float* A, const float* Bm, float* C, int M, int N, int K, int lda,
+                     int ldb, int ldc, const float* bias, const float* resid, int act, int accumulate, int bf16,
+                     int batch = 1, long long sA = 0, long long sB = 0, long long sC = 0) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = Bm; g.C = C; g.bias = bias; g.resid = resid; g.partial = w.gpart;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sA = sA; g.sB = sB; g.sC = sC; g.batch = batch; g.accumulate = accumulate; g.act = act; g.bf16 = bf16;
+    g.splitk = gemm_pick_splitk(M, N, K, batch, bf16);
+    HIPCHK(gemm_launch(g, s));
+    return 0;
+}
+
 static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* tb, const Ws& w, const void* x, int B,
                     int S, hipStream_t s) {
     const ddimx_config& f = c->cfg;
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
     const float eps = f.fnet_ln_eps;
+    const int bf = c->dtype == DT_BF16;
     HIPCHK(layernorm_launch(c->dtype, x, tb->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps, w.ln0, M,
                             width, s));
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = w.ln0; g.B = pf(c, packed, c->proj_w); g.C = w.X; g.bias = pf(c, packed, c->proj_b);
-    g.M = M; g.N = hid; g.K = width; g.lda = width; g.ldb = width; g.ldc = hid; g.batch = 1;
-    HIPCHK(gemm_f32_launch(g, s));
+    CHK(fnet_gemm(w, s, w.ln0, pf(c, packed, c->proj_w), w.X, M, hid, width, width, width, hid, pf(c, packed, c->proj_b),
+                  nullptr, 0, 0, bf));
     float* cur = w.X;
     float* other = w.Y;
     for (int i = 0; i < f.fnet_layers; ++i) {
         const ddimx_ctx::FL& L = c->fl[i];
         // Ut[b] = [C_H; S_H] * X[b]^T   -> [2*hid][S]
-        memset(&g, 0, sizeof(g));
-        g.A = tb->dft_hidden; g.B = cur; g.C = w.Ut;
-        g.M = 2 * hid; g.N = S; g.K = hid; g.lda = hid; g.ldb = hid; g.ldc = S;
-        g.sA = 0; g.sB = (long long)S * hid; g.sC = (long long)2 * hid * S; g.batch = B;
-        HIPCHK(gemm_f32_launch(g, s));
+        CHK(fnet_gemm(w, s, tb->dft_hidden, cur, w.Ut, 2 * hid, S, hid, hid, hid, S, nullptr, nullptr, 0, 0, 0, B, 0,
+                      (long long)S * hid, (long long)2 * hid * S));
         // Z[b] = C_S * Utc[b]^T ; Z[b] += (-S_S) * Uts[b]^T + X[b]   (Re(FFT2) + residual)
-        memset(&g, 0, sizeof(g));
-        g.A = tb->dft_seq; g.B = w.Ut; g.C = w.Z;
-        g.M = S; g.N = hid; g.K = S; g.lda = S; g.ldb = S; g.ldc = hid;
-        g.sA = 0; g.sB = (long long)2 * hid * S; g.sC = (long long)S * hid; g.batch = B;
-        HIPCHK(gemm_f32_launch(g, s));
-        g.A = tb->dft_seq + (size_t)S * S; g.B = w.Ut + (size_t)hid * S; g.accumulate = 1; g.resid = cur;
-        HIPCHK(gemm_f32_launch(g, s));
+        CHK(fnet_gemm(w, s, tb->dft_seq, w.Ut, w.Z, S, hid, S, S, S, hid, nullptr, nullptr, 0, 0, 0, B, 0,
+                      (long long)2 * hid * S, (long long)S * hid));
+        CHK(fnet_gemm(w, s, tb->dft_seq + (size_t)S * S, w.Ut + (size_t)hid * S, w.Z, S, hid, S, S, S, hid, nullptr, cur, 0, 1,
+                      0, B, 0, (long long)2 * hid * S, (long long)S * hid));
         HIPCHK(layernorm_launch(DT_F32, w.Z, nullptr, 1, pf(c, packed, L.ln1_w), pf(c, packed, L.ln1_b), eps, other, M, hid, s));
         // FFN
-        memset(&g, 0, sizeof(g));
-        g.A = other; g.B = pf(c, packed, L.w1); g.C = w.Hb; g.bias = pf(c, packed, L.b1); g.act = 1;
-        g.M = M; g.N = inter; g.K = hid; g.lda = hid; g.ldb = hid; g.ldc = inter; g.batch = 1;
-        HIPCHK(gemm_f32_launch(g, s));
-        memset(&g, 0, sizeof(g));
-        g.A = w.Hb; g.B = pf(c, packed, L.w2); g.C = w.Z; g.bias = pf(c, packed, L.b2); g.resid = other;
-        g.M = M; g.N = hid; g.K = inter; g.lda = inter; g.ldb = inter; g.ldc = hid; g.batch = 1;
-        HIPCHK(gemm_f32_launch(g, s));
+        CHK(fnet_gemm(w, s, other, pf(c, packed, L.w1), w.Hb, M, inter, hid, hid, hid, inter, pf(c, packed, L.b1), nullptr, 1, 0, bf));
+        CHK(fnet_gemm(w, s, w.Hb, pf(c, packed, L.w2), w.Z, M, hid, inter, inter, inter, hid, pf(c, packed, L.b2), other, 0, 0, bf));
         HIPCHK(layernorm_launch(DT_F32, w.Z, nullptr, 1, pf(c, packed, L.ln2_w), pf(c, packed, L.ln2_b), eps, cur, M, hid, s));
     }
-    memset(&g, 0, sizeof(g));
-    g.A = cur; g.B = pf(c, packed, c->cout_w); g.C = w.O; g.bias = pf(c, packed, c->cout_b);
-    g.M = M; g.N = width; g.K = hid; g.lda = hid; g.ldb = hid; g.ldc = width; g.batch = 1;
-    HIPCHK(gemm_f32_launch(g, s));
+    CHK(fnet_gemm(w, s, cur, pf(c, packed, c->cout_w), w.O, M, width, hid, hid, hid, width, pf(c, packed, c->cout_b), nullptr,
+                  0, 0, bf));
     return 0;
 }
 
@@ -473,6 +512,7 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         switch (p.kind) {
             case PK_COPY: HIPCHK(pack_copy_launch(src, (float*)dst, p.numel, s)); break;
             case PK_CONV: HIPCHK(pack_conv_launch(h->dtype, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
+            case PK_CONV_F32: HIPCHK(pack_conv_launch(DT_F32, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
             case PK_CONVT: HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s)); break;
             case PK_BIAS2:
                 HIPCHK(pack_copy_launch(src, (float*)dst, p.d0, s));
@@ -609,6 +649,13 @@ int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const floa
                       int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                       float* stats, int B, int H, int W, void* stream) {
     ConvCall k = {dtype, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
+    return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
+}
+int ddimx_debug_conv3x3_stamps(int dtype, int C, const void* x, const void* w, const float* chan_add, const float* in_scale,
+                                const float* in_shift, void* y, float* stats, unsigned long long* stamps, int B, int H, int W,
+                                void* stream) {
+    ConvCall k = {dtype, CONV3, C, C, x, w, nullptr, chan_add, C, in_scale, in_shift, XF_AFFINE_SILU, 1, nullptr, y, stats, B, H, W};
+    k.stamps = stamps;
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
 long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W) {

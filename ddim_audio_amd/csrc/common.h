@@ -61,6 +61,93 @@ template <> struct Piece<__bf16> {
     }
 };
 
+
+// ---- packed-f32 pairs: arithmetic on float2 vectors lowers to v_pk_mul/add/fma_f32 (one VALU issue per two
+// elements).  The element-wise prologue/epilogue of the conv kernels is VALU-issue bound, so this matters.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+__device__ __forceinline__ f32x2_t silu2(f32x2_t v) {
+    const f32x2_t t = v * (-1.4426950408889634f);
+    f32x2_t e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2_t d = e + 1.0f;
+    f32x2_t r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return v * r;
+}
+__device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+
+template <typename T> struct Pairs;  // 16-byte piece <-> float2 pairs
+template <> struct Pairs<float> {
+    static constexpr int N = 2;
+    static __device__ __forceinline__ void unpack(const uint4& v, f32x2_t* f) {
+        f[0].x = __uint_as_float(v.x); f[0].y = __uint_as_float(v.y);
+        f[1].x = __uint_as_float(v.z); f[1].y = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const f32x2_t* f) {
+        return make_uint4(__float_as_uint(f[0].x), __float_as_uint(f[0].y), __float_as_uint(f[1].x), __float_as_uint(f[1].y));
+    }
+};
+template <> struct Pairs<__bf16> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ f32x2_t up(uint32_t w) {
+        f32x2_t r;
+        r.x = __uint_as_float(w << 16);
+        r.y = __uint_as_float(w & 0xffff0000u);
+        return r;
+    }
+    static __device__ __forceinline__ void unpack(const uint4& v, f32x2_t* f) {
+        f[0] = up(v.x); f[1] = up(v.y); f[2] = up(v.z); f[3] = up(v.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const f32x2_t* f) {
+        return make_uint4(Piece<__bf16>::pk(f[0].x, f[0].y), Piece<__bf16>::pk(f[1].x, f[1].y),
+                          Piece<__bf16>::pk(f[2].x, f[2].y), Piece<__bf16>::pk(f[3].x, f[3].y));
+    }
+};
+
+
+// ---- buffer resources: hardware bounds check (offset >= num_records loads zeros / drops the store), so
+// padding and ragged tile edges need no branches around memory instructions ------------------------------
+typedef __attribute__((vector_size(16))) unsigned int u32x4_t;
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned off, const uint4& v) {
+    const u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
+}
+
+
+// ---- LDS-DMA (global -> LDS, 16 B per lane, no VGPR destination).  Written as inline asm on purpose: with the
+// builtin, hipcc orders every later ds_read behind the pending DMA with s_waitcnt vmcnt(0) (it cannot prove the
+// addresses disjoint), which serialises the ring.  As asm the instruction is invisible to the waitcnt pass; the
+// caller waits with a counted s_waitcnt vmcnt(N) and a barrier before any wave reads the bytes
+// (cdna_hip_programming.md section 5.7).  lds_addr: wave-uniform LDS byte address (lane i lands at +16*i).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<__bf16>(__bf16 v) { return (float)v; }

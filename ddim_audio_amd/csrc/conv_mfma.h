@@ -10,9 +10,13 @@
 //   epilogue : + bias, + per-sample channel vector (timestep embedding), SiLU, + skip tensor,
 //              per-channel sum / sum-of-squares partials for the NEXT GroupNorm (deterministic slabs).
 //
-// Work decomposition: a workgroup owns TH x TW output pixels (one sample) x NB output channels.
-// The transformed input halo tile stays resident in LDS for all taps; weights stream through LDS in
-// chunks (TPC taps x KC input channels), register-staged one chunk ahead of the MFMAs.
+// Work decomposition: a PERSISTENT workgroup walks `tiles_per_wg` consecutive tiles of one sample; a tile is
+// TH x TW output pixels x NB output channels.  While the MFMAs of tile i run, the halo of tile i+1 is already
+// in flight into registers (global_load_dwordx4, waited for only after the epilogue of tile i), so HBM latency
+// hides under compute.  The transformed halo tile stays resident in LDS for all taps; weights stay resident in
+// LDS for the whole workgroup when all taps fit in one chunk, else they stream through LDS in chunks (TPC taps
+// x KC input channels), register-staged one chunk ahead of the MFMAs.  GroupNorm statistics accumulate in
+// registers across the workgroup's tiles: one deterministic partial per workgroup.
 // MFMA orientation: A = weights (rows = cout), B = pixels (cols = pixel), so the accumulator holds,
 // per lane, 4 consecutive couts of one pixel per register quad -> packed 8/16-byte LDS writes in the
 // epilogue, then fully coalesced 16-byte global stores of whole NHWC pixel rows.
@@ -20,6 +24,8 @@
 // T = __bf16 : v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  T = float : v_mfma_f32_32x32x2_f32
 // (exact fp32 FMA chain; the parity mode).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace ddimx {
@@ -43,9 +49,12 @@ struct ConvArgs {
     int B, Hin, Win;
     int Hv, Wv;             // virtual output grid (UP4: = input grid; else = output grid)
     int tiles_x, tiles_y;
+    int tiles_per_wg;       // consecutive tiles (x-major) walked by one workgroup
+    int wgs_per_sample;     // ceil(tiles_x*tiles_y / tiles_per_wg); grid.x = B * wgs_per_sample
+    unsigned long long* stamps;  // diagnostic builds only (-DDDIMX_STAMP): [grid.x][16] per-phase cycle sums
 };
 
-template <typename T, int CIN_, int NOUT_, int NB_, int MODE_, int TH_, int TW_, int WM_, int WN_, int KC_, int TPC_>
+template <typename T, int CIN_, int NOUT_, int NB_, int MODE_, int TH_, int TW_, int WM_, int WN_, int KC_, int TPC_, int OVL_ = 0>
 struct ConvCfg {
     typedef T elem;
     static constexpr int CIN = CIN_, NOUT = NOUT_, NB = NB_, MODE = MODE_, TH = TH_, TW = TW_, WM = WM_, WN = WN_,
@@ -74,9 +83,25 @@ struct ConvCfg {
     static constexpr int NWBUF = NCHUNKS > 1 ? 2 : 1;
     static constexpr int OSTRIDE = NB * ES + 16;
     static constexpr int OUT_BYTES = P * OSTRIDE;
-    static constexpr int MAIN_BYTES = HALO_BYTES + NWBUF * WCHUNK_BYTES;
-    static constexpr int RED_BYTES = NWAVES * NB * 2 * 4;  // per-wave per-channel (sum, sumsq)
-    static constexpr int LDS_BYTES = (MAIN_BYTES > OUT_BYTES + RED_BYTES ? MAIN_BYTES : OUT_BYTES + RED_BYTES);
+    // streaming weights: 3-stage LDS-DMA ring (global_load_lds, 1 KiB per wave-instruction, every wave issues
+    // the same number DMA_PER_WAVE so a counted vmcnt is exact); resident weights: one register-staged chunk
+    static constexpr int WROWP = KC / EPB + 1;                        // 16-B pieces per padded LDS row
+    static constexpr int CHUNK_PIECES = TPC * NB * WROWP;
+    static constexpr int DMA_INSTR = (CHUNK_PIECES + 63) / 64;
+    static constexpr int DMA_PER_WAVE = (DMA_INSTR + NWAVES - 1) / NWAVES;
+    static constexpr int WSTAGE_BYTES = DMA_INSTR * 1024;  // surplus DMA slots of the last round go to a dummy KiB
+    static constexpr int NSTAGE = 3;
+    static constexpr int WBUF_BYTES = NCHUNKS > 1 ? NSTAGE * WSTAGE_BYTES + 1024 : WCHUNK_BYTES;
+    static constexpr int RED_BYTES = NWAVES * NB * 2 * 4;  // per-wave per-channel (sum, sumsq); overlays wbuf/halo at the end
+    static constexpr bool RESIDENT_W = NCHUNKS == 1;       // all taps in one chunk: loaded once per workgroup
+    // the epilogue's output tile gets its own LDS region when everything fits in 80 KiB (2 workgroups per CU);
+    // otherwise it overlays the halo region (two more barriers per tile)
+    // OVL_: 0 = separate when it fits, 1 = force overlay (smaller LDS, more workgroups per CU), 2 = force separate
+    static constexpr bool SEPARATE_OUT = OVL_ == 2 || (OVL_ == 0 && WBUF_BYTES + HALO_BYTES + OUT_BYTES <= 80 * 1024);
+    static constexpr int HO_BYTES = SEPARATE_OUT ? HALO_BYTES + OUT_BYTES : (HALO_BYTES > OUT_BYTES ? HALO_BYTES : OUT_BYTES);
+    static constexpr int ADD_BYTES = NB * 4;  // per-cout epilogue addend (bias + timestep embedding) of this sample
+    static constexpr int LDS_RAW = ADD_BYTES + WBUF_BYTES + HO_BYTES;
+    static constexpr int LDS_BYTES = LDS_RAW > RED_BYTES ? LDS_RAW : RED_BYTES;
     static constexpr int KG = KC * ES / 32;  // 32-byte k-groups per tap per chunk
     static constexpr int WPIECES = TPC * NB * (KC / EPB);
     static constexpr int WPT = (WPIECES + NTHREADS - 1) / NTHREADS;  // weight pieces per thread per chunk
@@ -84,6 +109,9 @@ struct ConvCfg {
     static constexpr int LPP = next_pow2(CPP);  // lanes cooperating on one input pixel
     static constexpr int OPP = NB / EPB;        // 16-B pieces per output pixel (this WG's channels)
     static constexpr int OLPP = next_pow2(OPP);
+    static constexpr int NPIX = IH * IW;        // halo pixels
+    static constexpr int PPP = NTHREADS / LPP;  // halo pixels staged per pass
+    static constexpr int HPT = (NPIX + PPP - 1) / PPP;  // halo pieces per thread (prefetch registers)
 
     static_assert(P % (32 * WM) == 0 && MT >= 1, "pixel tile must split into 32-pixel MFMA blocks");
     static_assert(NB % (32 * WN) == 0 && NT >= 1, "cout block must split into 32-row MFMA blocks");
@@ -96,6 +124,22 @@ struct ConvCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget (160 KiB per CU)");
     static_assert(LPP <= NTHREADS && OLPP <= 64, "piece lanes");
     static_assert(NTHREADS % LPP == 0 && NTHREADS % OLPP == 0, "");
+    // prefetch the next halo into registers only where it fits beside the accumulators (the HBM-bound, small-C
+    // configurations); elsewhere the halo is staged synchronously after the epilogue
+    // per-piece offsets are hoisted out of the tile loop (2 registers per piece) when there are few pieces
+    static constexpr bool HOIST = HPT <= 16;
+    static constexpr bool PREFETCH = HOIST && HPT * 6 + NT * MT * 16 <= 100;
+    static constexpr int HREGS = (PREFETCH || HOIST) ? HPT : 4;
+    static constexpr int HOFF = HOIST ? HPT : 1;
+    // occupancy the LDS footprint allows, as waves per SIMD (2nd __launch_bounds__ argument): keeps the register
+    // allocator from trading occupancy for scheduling freedom
+    static constexpr int WG_PER_CU = (160 * 1024) / LDS_BYTES < 1 ? 1 : (160 * 1024) / LDS_BYTES;
+    static constexpr int W_LDS = (WG_PER_CU * NWAVES + 3) / 4 > 8 ? 8 : (WG_PER_CU * NWAVES + 3) / 4;
+    static constexpr int REG_EST = NT * MT * 16 + HREGS * 4 + WPT * 4 + (NT + MT) * 4 + 72;
+    static constexpr int W_REG = 512 / ((REG_EST + 7) / 8 * 8) < 1 ? 1 : 512 / ((REG_EST + 7) / 8 * 8);
+    static constexpr int MINW_RAW = W_LDS < W_REG ? W_LDS : W_REG;
+    // an 8-wave workgroup occupies 2 waves per SIMD: 3 is not a useful target
+    static constexpr int MINW = (NWAVES == 8 && MINW_RAW == 3) ? 2 : MINW_RAW;
 };
 
 template <typename T> struct Mma;
@@ -145,232 +189,425 @@ __device__ __forceinline__ void conv_w_store(const uint4 (&wreg)[C::WPT], char* 
     }
 }
 
+// In-kernel phase stamps (diagnostic build libddimx_stamp.so only; the product library never executes one).
+#ifdef DDIMX_STAMP
+#define DDIMX_STAMP_DECL unsigned long long st_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, st_last = 0; { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); }
+#define DDIMX_STAMP_AT(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DDIMX_STAMP_FLUSH() do { if (a.stamps && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) a.stamps[((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 12 + k_] = st_acc[k_]; } } while (0)
+#else
+#define DDIMX_STAMP_DECL
+#define DDIMX_STAMP_AT(k)
+#define DDIMX_STAMP_FLUSH()
+#endif
+
 template <class C>
-__global__ void __launch_bounds__(C::NTHREADS) conv_mfma_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const ConvArgs a) {
     typedef typename C::elem T;
     constexpr int ES = C::ES, EPB = C::EPB, CIN = C::CIN, NB = C::NB, NOUT = C::NOUT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const halo = smem;
-    char* const wbuf = smem + C::HALO_BYTES;
+    float* const addv = (float*)smem;
+    char* const wbuf = smem + C::ADD_BYTES;
+    char* const halo = wbuf + C::WBUF_BYTES;
+    char* const otile = C::SEPARATE_OUT ? halo + C::HALO_BYTES : halo;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % C::WM, wn = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;
 
-    const int tx = blockIdx.x % a.tiles_x;
-    const int ty = (blockIdx.x / a.tiles_x) % a.tiles_y;
-    const int bs = blockIdx.x / (a.tiles_x * a.tiles_y);
+    const int wg = blockIdx.x % a.wgs_per_sample;
+    const int bs = blockIdx.x / a.wgs_per_sample;
     const int cout0 = blockIdx.y * NB;
     const int cls = blockIdx.z;  // UP4 row-parity class; 0 otherwise
-    const int y0 = ty * C::TH, x0 = tx * C::TW;
-    const int hy0 = y0 * C::SXY - 1, hx0 = x0 * C::SXY - 1;
+    const int ntile_s = a.tiles_x * a.tiles_y;
+    const int t_begin = wg * a.tiles_per_wg;
+    const int t_end = (t_begin + a.tiles_per_wg < ntile_s) ? t_begin + a.tiles_per_wg : ntile_s;
 
     const T* const wbase = (const T*)a.w + (size_t)cls * C::NTAPS * NOUT * CIN;
 
-    // ---- weight chunk staging (global -> registers -> LDS), one chunk ahead of the MFMAs ----------
-    uint4 wreg[C::WPT];
-#define W_LOAD(ch) conv_w_load<C>(wreg, wbase, cout0, tid, (ch))
-#define W_STORE(buf) conv_w_store<C>(wreg, wbuf + (buf) * C::WCHUNK_BYTES, tid)
-    W_LOAD(0);
-
-    // ---- stage the input halo tile, applying the GroupNorm affine (+SiLU) on the way ---------------
-    {
-        constexpr int LPP = C::LPP, PPP = C::NTHREADS / LPP, NPIX = C::IH * C::IW;
-        const int c = tid % LPP, pslot = tid / LPP;
-        const bool cvalid = c < C::CPP;
-        float sc[EPB], sh[EPB];
-        if (a.xf != XF_NONE && cvalid) {
+    // ---- weights.  Resident (all taps in one chunk): loaded once through registers.  Streaming: a 3-stage
+    // LDS-DMA ring that runs continuously across tiles -- while chunk g is multiplied, chunk g+1 is landing and
+    // chunk g+2 is being issued; no VGPRs are spent on staging.  Per-lane source offsets (relative to the
+    // chunk base) are tile- and chunk-invariant and hoisted here; the LDS destination of DMA instruction q is
+    // stage_base + q * 1 KiB (wave-uniform), lanes that map to row padding re-read the chunk base.
+    uint4 wregA[C::RESIDENT_W ? C::WPT : 1];
+    unsigned wrel[C::RESIDENT_W ? 1 : C::DMA_PER_WAVE];
+    if constexpr (!C::RESIDENT_W) {
 #pragma unroll
-            for (int j = 0; j < EPB; ++j) {
-                sc[j] = a.in_scale[(size_t)bs * CIN + c * EPB + j];
-                sh[j] = a.in_shift[(size_t)bs * CIN + c * EPB + j];
-            }
-        }
-        const T* const inb = (const T*)a.in + (size_t)bs * a.Hin * a.Win * CIN + c * EPB;
-        constexpr int UNR = 4;
-        for (int base = 0; base < NPIX; base += PPP * UNR) {
-            uint4 v[UNR];
-            int off[UNR];
-            bool ok[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int pix = base + u * PPP + pslot;
-                const int iy = pix / C::IW, ix = pix % C::IW;
-                const int gy = hy0 + iy, gx = hx0 + ix;
-                const bool inr = cvalid && pix < NPIX;
-                ok[u] = inr && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-                off[u] = inr ? iy * C::ROWSTRIDE + ix * C::PSTRIDE + c * 16 : -1;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (ok[u]) v[u] = *(const uint4*)(inb + ((size_t)gy * a.Win + gx) * CIN);
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                if (off[u] < 0) continue;
-                if (ok[u] && a.xf != XF_NONE) {
-                    float f[EPB];
-                    Piece<T>::unpack(v[u], f);
-#pragma unroll
-                    for (int j = 0; j < EPB; ++j) {
-                        float t = fmaf(f[j], sc[j], sh[j]);
-                        f[j] = (a.xf == XF_AFFINE_SILU) ? silu_f(t) : t;
-                    }
-                    v[u] = Piece<T>::pack(f);
-                }
-                *(uint4*)(halo + off[u]) = v[u];
-            }
+        for (int j = 0; j < C::DMA_PER_WAVE; ++j) {
+            const int idx = (wave + j * C::NWAVES) * 64 + lane;
+            const int tp = idx / (NB * C::WROWP), rem = idx % (NB * C::WROWP);
+            const int row = rem / C::WROWP, pc = rem % C::WROWP;
+            const bool real = idx < C::CHUNK_PIECES && pc < C::WROWP - 1;
+            wrel[j] = real ? (unsigned)(((tp * NOUT + row) * CIN + pc * EPB) * ES) : 0u;
         }
     }
-    W_STORE(0);
-    __syncthreads();
+    // wave-uniform LDS byte address of this wave's first DMA slot (readfirstlane: threadIdx-derived values are
+    // not provably uniform to the compiler)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned wbuf_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wbuf) + (unsigned)wave_u * 1024u);
+    const unsigned wdummy_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wbuf) + (unsigned)(C::NSTAGE * C::WSTAGE_BYTES));
+    auto dma_issue = [&](int ch, int stage) __attribute__((always_inline)) {
+        if constexpr (!C::RESIDENT_W) {
+            const int tap0 = (ch / C::KSPLIT) * C::TPC, kc0 = (ch % C::KSPLIT) * C::KC;
+            const char* cbase = (const char*)(wbase + ((size_t)tap0 * NOUT + cout0) * CIN + kc0);
+            const unsigned dst0 = wbuf_lds + stage * C::WSTAGE_BYTES;
+#pragma unroll
+            for (int j = 0; j < C::DMA_PER_WAVE; ++j) {
+                // every wave issues DMA_PER_WAVE instructions (exact counted waits); slots past the chunk land in
+                // the dummy KiB behind the ring
+                const bool real_slot = (j + 1) * C::NWAVES <= C::DMA_INSTR || wave_u + j * C::NWAVES < C::DMA_INSTR;
+                lds_dma16(cbase + wrel[j], __builtin_amdgcn_readfirstlane(real_slot ? dst0 + j * C::NWAVES * 1024 : wdummy_lds));
+            }
+        }
+    };
 
-    // ---- main loop ---------------------------------------------------------------------------------
-    f32x16_t acc[C::NT][C::MT];
+    // ---- halo staging: per-thread constants (one thread = one 16-byte channel piece of a pixel slot) -----
+    const int hc = tid % C::LPP, hslot = tid / C::LPP;
+    const bool hvalid = hc < C::CPP;
+    constexpr int NP = EPB / 2;  // float2 pairs per 16-byte piece
+    f32x2_t sc[NP], sh[NP];
 #pragma unroll
-    for (int n = 0; n < C::NT; ++n)
+    for (int j = 0; j < NP; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+    if (a.xf != XF_NONE && hvalid) {
 #pragma unroll
-        for (int m = 0; m < C::MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+        for (int j = 0; j < NP; ++j) {
+            sc[j] = *(const f32x2_t*)(a.in_scale + (size_t)bs * CIN + hc * EPB + 2 * j);
+            sh[j] = *(const f32x2_t*)(a.in_shift + (size_t)bs * CIN + hc * EPB + 2 * j);
+        }
+    }
+    // per-sample buffer resources (wave-uniform: built from kernel arguments and blockIdx only)
+    const unsigned in_bytes = (unsigned)((size_t)a.Hin * a.Win * CIN * ES);
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc((const T*)a.in + (size_t)bs * a.Hin * a.Win * CIN, in_bytes);
 
+    uint4 hreg[C::HREGS];
+    unsigned hok = 0;
+    // tile-invariant per-piece offsets: global byte offset relative to the halo origin, LDS byte offset
+    unsigned hrel[C::HOFF];
+    int hlds[C::HOFF];
+    if constexpr (C::HOIST) {
+#pragma unroll
+        for (int i = 0; i < C::HPT; ++i) {
+            const int pix = i * C::PPP + hslot;
+            const bool in_tile = hvalid && (i < C::HPT - 1 || pix < C::NPIX);
+            const int iy = pix / C::IW, ix = pix % C::IW;
+            hrel[i] = in_tile ? (unsigned)(((iy * a.Win + ix) * CIN + hc * EPB) * ES) : 0x80000000u;  // -> out of bounds
+            hlds[i] = in_tile ? iy * C::ROWSTRIDE + ix * C::PSTRIDE + hc * 16 : -1;
+        }
+    }
+    // one halo piece, general form: branch-free buffer load; padding / out-of-range pieces use an
+    // out-of-bounds offset -> zeros
+    auto piece_load = [&](int t, int i, uint4& v) __attribute__((always_inline)) -> bool {
+        const int pix = i * C::PPP + hslot;
+        const int hy0 = (t / a.tiles_x) * C::TH * C::SXY - 1, hx0 = (t % a.tiles_x) * C::TW * C::SXY - 1;
+        const int gy = hy0 + pix / C::IW, gx = hx0 + pix % C::IW;
+        const bool ok = hvalid && (i < C::HPT - 1 || pix < C::NPIX) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        v = buf_load16(in_rsrc, ok ? (unsigned)(((gy * a.Win + gx) * CIN + hc * EPB) * ES) : kOOB);
+        return ok;
+    };
+    // all pieces of tile t: interior tiles (halo entirely inside the image) add one scalar base to the hoisted
+    // offsets; border tiles take the general form.  Sets hok (bit i = piece i holds real data).
+    auto halo_load_all = [&](int t) __attribute__((always_inline)) {
+        const int hy0 = (t / a.tiles_x) * C::TH * C::SXY - 1, hx0 = (t % a.tiles_x) * C::TW * C::SXY - 1;
+        const bool interior = hy0 >= 0 && hx0 >= 0 && hy0 + C::IH <= a.Hin && hx0 + C::IW <= a.Win;  // wave-uniform
+        if (interior) {
+            const unsigned base = (unsigned)((hy0 * a.Win + hx0) * CIN * ES);
+#pragma unroll
+            for (int i = 0; i < C::HPT; ++i) hreg[i] = buf_load16(in_rsrc, base + hrel[i]);
+            hok = 0xFFFFFFFFu;
+        } else {
+            hok = 0;
+#pragma unroll
+            for (int i = 0; i < C::HPT; ++i)
+                if (piece_load(t, i, hreg[i])) hok |= 1u << i;
+        }
+    };
+    // GroupNorm affine (+SiLU) in registers, zero the padding AFTER the transform (select, no branch), one LDS
+    // write.  XF is a compile-time tag (the caller branches once, wave-uniformly, on a.xf).
+    auto piece_xf = [&](auto xf_tag, uint4 v, bool ok) __attribute__((always_inline)) -> uint4 {
+        constexpr int XF = decltype(xf_tag)::value;
+        if (XF != XF_NONE) {
+            f32x2_t f[NP];
+            Pairs<T>::unpack(v, f);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                f[j] = fma2(f[j], sc[j], sh[j]);
+                if (XF == XF_AFFINE_SILU) f[j] = silu2(f[j]);
+            }
+            const uint4 tv = Pairs<T>::pack(f);
+            v.x = ok ? tv.x : 0u; v.y = ok ? tv.y : 0u; v.z = ok ? tv.z : 0u; v.w = ok ? tv.w : 0u;
+        }
+        return v;
+    };
+    auto piece_store = [&](auto xf_tag, int i, uint4 v, bool ok) __attribute__((always_inline)) {
+        const int pix = i * C::PPP + hslot;
+        v = piece_xf(xf_tag, v, ok);
+        if (i < C::HPT - 1 || pix < C::NPIX)
+            *(uint4*)(halo + (pix / C::IW) * C::ROWSTRIDE + (pix % C::IW) * C::PSTRIDE + hc * 16) = v;
+    };
+    // issue the global loads of tile t's halo (no wait) -- prefetch configurations only
+    auto halo_issue = [&](int t) __attribute__((always_inline)) {
+        if constexpr (C::PREFETCH) {
+            halo_load_all(t);
+            // pin the issue point: without this LLVM sinks the loads below the MFMA block, next to their use
+            // (no waitcnt is implied: nothing here reads the destination registers)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // write tile t's halo to LDS (from the prefetch registers, or loading it now)
+    auto halo_commit_xf = [&](auto xf_tag, int t) __attribute__((always_inline)) {
+        if (!hvalid) return;  // lanes beyond the channel pieces of a pixel (C/8 not a power of two)
+        if constexpr (C::HOIST) {
+            if constexpr (!C::PREFETCH) halo_load_all(t);
+            if (hok == 0xFFFFFFFFu) {  // interior tile: every piece is real data
+#pragma unroll
+                for (int i = 0; i < C::HPT; ++i)
+                    if (i < C::HPT - 1 || hlds[i] >= 0) *(uint4*)(halo + hlds[i]) = piece_xf(xf_tag, hreg[i], true);
+            } else {
+#pragma unroll
+                for (int i = 0; i < C::HPT; ++i)
+                    if (i < C::HPT - 1 || hlds[i] >= 0) *(uint4*)(halo + hlds[i]) = piece_xf(xf_tag, hreg[i], (hok >> i) & 1u);
+            }
+        } else {
+#pragma unroll 1
+            for (int i0 = 0; i0 < C::HPT; i0 += 4) {
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ok[u] = (i0 + u < C::HPT) && piece_load(t, i0 + u, hreg[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < C::HPT) piece_store(xf_tag, i0 + u, hreg[u], ok[u]);
+            }
+        }
+    };
+    auto halo_commit = [&](int t) __attribute__((always_inline)) {
+        if (a.xf == XF_AFFINE_SILU) halo_commit_xf(std::integral_constant<int, XF_AFFINE_SILU>(), t);
+        else if (a.xf == XF_AFFINE) halo_commit_xf(std::integral_constant<int, XF_AFFINE>(), t);
+        else halo_commit_xf(std::integral_constant<int, XF_NONE>(), t);
+    };
+
+    // ---- per-lane MFMA operand offsets (tile independent) ----------------------------------------------
     int pixoff[C::MT];
 #pragma unroll
     for (int m = 0; m < C::MT; ++m) {
         const int p = (wm * C::MT + m) * 32 + l31;
-        const int py = p / C::TW, px = p % C::TW;
-        pixoff[m] = py * C::SXY * C::ROWSTRIDE + px * C::SXY * C::PSTRIDE + h * 16;
+        pixoff[m] = (p / C::TW) * C::SXY * C::ROWSTRIDE + (p % C::TW) * C::SXY * C::PSTRIDE + h * 16;
     }
     const int woff = (wn * C::NT * 32 + l31) * C::WROW + h * 16;
 
-    for (int ch = 0; ch < C::NCHUNKS; ++ch) {
-        if (ch + 1 < C::NCHUNKS) W_LOAD(ch + 1);
-        const char* wb = wbuf + (ch & 1) * C::WCHUNK_BYTES + woff;
-        const int tap0 = (ch / C::KSPLIT) * C::TPC;
-        const int kc0 = (ch % C::KSPLIT) * C::KC;
+    // ---- epilogue constants ---------------------------------------------------------------------------------
+    const int oc = tid % C::OLPP, oslot = tid / C::OLPP;
+    const bool ovalid = oc < C::OPP;
+    f32x2_t st_s[NP], st_q[NP];
 #pragma unroll
-        for (int tp = 0; tp < C::TPC; ++tp) {
-            const int tap = tap0 + tp;
-            const int dy = (C::MODE == UP4 ? cls : 0) + tap / C::TAPW, dx = tap % C::TAPW;
-            const int hoff = dy * C::ROWSTRIDE + dx * C::PSTRIDE + kc0 * ES;
-#pragma unroll
-            for (int kg = 0; kg < C::KG; ++kg) {
-                uint4 bf[C::MT], af[C::NT];
-#pragma unroll
-                for (int m = 0; m < C::MT; ++m) bf[m] = *(const uint4*)(halo + pixoff[m] + hoff + kg * 32);
-#pragma unroll
-                for (int n = 0; n < C::NT; ++n)
-                    af[n] = *(const uint4*)(wb + (tp * NB + n * 32) * C::WROW + kg * 32);
-#pragma unroll
-                for (int n = 0; n < C::NT; ++n)
-#pragma unroll
-                    for (int m = 0; m < C::MT; ++m) Mma<T>::run(af[n], bf[m], acc[n][m]);
-            }
-        }
-        if (ch + 1 < C::NCHUNKS) W_STORE((ch + 1) & 1);
-        __syncthreads();
-    }
+    for (int j = 0; j < NP; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+    const int Hout = (C::MODE == UP4) ? 2 * a.Hv : a.Hv;
+    const size_t rowlen = (size_t)a.Wv * NOUT;  // elements per output row (UP4: Wv*2*Cprev = Wout*Cprev)
+    const unsigned out_bytes = (unsigned)((size_t)Hout * rowlen * ES);
+    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc((T*)a.out + (size_t)bs * Hout * rowlen, out_bytes);
+    const __amdgpu_buffer_rsrc_t skip_rsrc = make_rsrc(a.skip ? (const T*)a.skip + (size_t)bs * Hout * rowlen : (const T*)a.out, a.skip ? out_bytes : 0u);
 
-    // ---- epilogue 1: accumulators -> (+bias, +chan_add, act) -> LDS out tile [pixel][cout] ---------
-    char* const otile = smem;  // overlays halo/weights: every wave is past the final barrier
-    float* const red = (float*)(smem + C::OUT_BYTES);
-#pragma unroll
-    for (int n = 0; n < C::NT; ++n) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cl = (wn * C::NT + n) * 32 + q * 8 + h * 4;  // local cout of this register quad
-            float add[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = 0.f;
-                if (a.bias) v += a.bias[cout0 + cl + i];
-                if (a.chan_add) v += a.chan_add[(size_t)bs * a.chan_add_stride + cout0 + cl + i];
-                add[i] = v;
-            }
-#pragma unroll
-            for (int m = 0; m < C::MT; ++m) {
-                const int p = (wm * C::MT + m) * 32 + l31;
-                float f[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc[n][m][q * 4 + i] + add[i];
-                    f[i] = a.act ? silu_f(v) : v;
-                }
-                char* dst = otile + p * C::OSTRIDE + cl * ES;
-                if constexpr (ES == 4) {
-                    *(uint4*)dst = Piece<float>::pack(f);
-                } else {
-                    *(uint2*)dst = make_uint2(Piece<__bf16>::pk(f[0], f[1]), Piece<__bf16>::pk(f[2], f[3]));
-                }
-            }
-        }
+    // ---- prologue: resident weights (if they fit in one chunk) and the first halo ------------------------
+    int wstage = 0;  // ring stage holding the chunk about to be multiplied
+    if constexpr (C::RESIDENT_W) {
+        conv_w_load<C>(wregA, wbase, cout0, tid, 0);
+        conv_w_store<C>(wregA, wbuf, tid);
+    } else {
+        dma_issue(0, 0);
+        dma_issue(1 % C::NCHUNKS, 1);
     }
+    for (int i = tid; i < NB; i += C::NTHREADS) {
+        float v = 0.f;
+        if (a.bias) v += a.bias[cout0 + i];
+        if (a.chan_add) v += a.chan_add[(size_t)bs * a.chan_add_stride + cout0 + i];
+        addv[i] = v;
+    }
+    halo_issue(t_begin);
+    halo_commit(t_begin);
     __syncthreads();
+    DDIMX_STAMP_DECL
 
-    // ---- epilogue 2: coalesced stores of whole pixel rows, + skip, per-channel stats ----------------
-    {
-        constexpr int OLPP = C::OLPP, PPP = C::NTHREADS / OLPP;
-        const int c = tid % OLPP, pslot = tid / OLPP;
-        const bool cvalid = c < C::OPP;
-        float s[EPB], q2[EPB];
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const int y0 = (t / a.tiles_x) * C::TH, x0 = (t % a.tiles_x) * C::TW;
+        if (t + 1 < t_end) halo_issue(t + 1);  // in flight during the MFMAs below
+        DDIMX_STAMP_AT(0);
+
+        f32x16_t acc[C::NT][C::MT];
 #pragma unroll
-        for (int j = 0; j < EPB; ++j) s[j] = q2[j] = 0.f;
-        const int Hout = (C::MODE == UP4) ? 2 * a.Hv : a.Hv;
-        const size_t rowlen = (size_t)a.Wv * NOUT;  // elements per output row (UP4: Wv*2*Cprev = Wout*Cprev)
-        for (int p = pslot; p < C::P; p += PPP) {
-            const int py = p / C::TW, px = p % C::TW;
-            const int vy = y0 + py, vx = x0 + px;
-            if (!cvalid || vy >= a.Hv || vx >= a.Wv) continue;
-            const int oy = (C::MODE == UP4) ? 2 * vy + cls : vy;
-            const size_t g = ((size_t)bs * Hout + oy) * rowlen + (size_t)vx * NOUT + cout0 + c * EPB;
-            uint4 v = *(const uint4*)(otile + p * C::OSTRIDE + c * 16);
-            float f[EPB];
-            Piece<T>::unpack(v, f);
-            if (a.skip) {
-                float k[EPB];
-                Piece<T>::unpack(*(const uint4*)((const T*)a.skip + g), k);
+        for (int n = 0; n < C::NT; ++n)
 #pragma unroll
-                for (int j = 0; j < EPB; ++j) f[j] += k[j];
-                v = Piece<T>::pack(f);
-                Piece<T>::unpack(v, f);  // statistics of the values as stored
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+
+        // one chunk: MFMAs over TPC taps x KC channels from LDS buffer `buf`
+        auto chunk_mma = [&](int ch, int buf) __attribute__((always_inline)) {
+            const char* wb = wbuf + buf * C::WSTAGE_BYTES + woff;
+            const int tap0 = (ch / C::KSPLIT) * C::TPC;
+            const int kc0 = (ch % C::KSPLIT) * C::KC;
+#pragma unroll
+            for (int tp = 0; tp < C::TPC; ++tp) {
+                const int tap = tap0 + tp;
+                const int dy = (C::MODE == UP4 ? cls : 0) + tap / C::TAPW, dx = tap % C::TAPW;
+                const int hoff = dy * C::ROWSTRIDE + dx * C::PSTRIDE + kc0 * ES;
+#pragma unroll
+                for (int kg = 0; kg < C::KG; ++kg) {
+                    uint4 bf[C::MT], af[C::NT];
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m) bf[m] = *(const uint4*)(halo + pixoff[m] + hoff + kg * 32);
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n)
+                        af[n] = *(const uint4*)(wb + (tp * NB + n * 32) * C::WROW + kg * 32);
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                        for (int m = 0; m < C::MT; ++m) Mma<T>::run(af[n], bf[m], acc[n][m]);
+                }
             }
-            *(uint4*)((T*)a.out + g) = v;
-#pragma unroll
-            for (int j = 0; j < EPB; ++j) {
-                s[j] += f[j];
-                q2[j] = fmaf(f[j], f[j], q2[j]);
+        };
+        if (C::RESIDENT_W) {
+            chunk_mma(0, 0);
+        } else {
+#pragma unroll 1
+            for (int ch = 0; ch < C::NCHUNKS; ++ch) {
+                const int s2 = wstage >= 1 ? wstage - 1 : 2;  // (wstage + 2) % 3: free since the last barrier
+                dma_issue((ch + 2) % C::NCHUNKS, s2);
+                chunk_mma(ch, wstage);
+                // this wave's part of chunk g+1 has landed once all but its DMA_PER_WAVE youngest VM ops are done
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DMA_PER_WAVE) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                wstage = wstage == 2 ? 0 : wstage + 1;
             }
         }
-        if (a.stats) {  // uniform branch
-            // lanes with equal c inside a wave: xor-reduce over the pixel-slot bits of the lane id
+        DDIMX_STAMP_AT(1);
+        if (C::RESIDENT_W) __syncthreads();  // barrier A: every wave is done reading this tile's halo
+        DDIMX_STAMP_AT(2);
+
+        // ---- epilogue 1: accumulators -> (+bias, +chan_add, act) -> LDS out tile [pixel][cout] ------------
+        auto epi1 = [&](auto act_tag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int o = OLPP; o < 64; o <<= 1) {
+            for (int n = 0; n < C::NT; ++n) {
 #pragma unroll
-                for (int j = 0; j < EPB; ++j) {
-                    s[j] += __shfl_xor(s[j], o, 64);
-                    q2[j] += __shfl_xor(q2[j], o, 64);
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = (wn * C::NT + n) * 32 + q * 8 + h * 4;  // local cout of this register quad
+                    const float4 av = *(const float4*)(addv + cl);
+                    const f32x2_t a01 = {av.x, av.y}, a23 = {av.z, av.w};
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m) {
+                        const int p = (wm * C::MT + m) * 32 + l31;
+                        f32x2_t v01 = {acc[n][m][q * 4 + 0], acc[n][m][q * 4 + 1]};
+                        f32x2_t v23 = {acc[n][m][q * 4 + 2], acc[n][m][q * 4 + 3]};
+                        v01 += a01;
+                        v23 += a23;
+                        if (ACT) { v01 = silu2(v01); v23 = silu2(v23); }
+                        char* dst = otile + p * C::OSTRIDE + cl * ES;
+                        if constexpr (ES == 4) {
+                            *(float4*)dst = make_float4(v01.x, v01.y, v23.x, v23.y);
+                        } else {
+                            *(uint2*)dst = make_uint2(Piece<__bf16>::pk(v01.x, v01.y), Piece<__bf16>::pk(v23.x, v23.y));
+                        }
+                    }
                 }
             }
-            if (lane < OLPP && cvalid) {
+        };
+        if (a.act) epi1(std::integral_constant<int, 1>()); else epi1(std::integral_constant<int, 0>());
+        DDIMX_STAMP_AT(3);
+        if (C::SEPARATE_OUT && t + 1 < t_end) halo_commit(t + 1);  // halo region is free: stage the next tile now
+        DDIMX_STAMP_AT(4);
+        __syncthreads();                                     // barrier B: out tile (and next halo) visible
+        DDIMX_STAMP_AT(5);
+
+        // ---- epilogue 2: coalesced stores of whole pixel rows, + skip, per-channel statistics --------------
+        // FULL tiles (entirely inside the image) need no per-lane validity; ragged ones drop stores through the
+        // buffer bounds check and mask their statistics.
+        auto epi2 = [&](auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            constexpr int STEP = C::NTHREADS / C::OLPP;          // pixels per pass
+            constexpr int NPASS = (C::P + STEP - 1) / STEP;
+            if (!ovalid) return;
+            const unsigned rowb = (unsigned)(a.Wv * NOUT * ES);  // bytes per virtual output row
+            const unsigned cbase = (unsigned)((cout0 + oc * EPB) * ES);
 #pragma unroll
-                for (int j = 0; j < EPB; ++j) {
-                    red[(wave * NB + c * EPB + j) * 2 + 0] = s[j];
-                    red[(wave * NB + c * EPB + j) * 2 + 1] = q2[j];
+            for (int k = 0; k < NPASS; ++k) {
+                const int p = oslot + k * STEP;                  // TW is a power of two: shifts and masks
+                if (C::P % STEP != 0 && p >= C::P) break;
+                const int vy = y0 + p / C::TW, vx = x0 + p % C::TW;
+                const bool valid = FULL || (vy < a.Hv && vx < a.Wv);
+                const unsigned oy = (C::MODE == UP4) ? 2u * vy + cls : (unsigned)vy;
+                const unsigned off = valid ? oy * rowb + (unsigned)vx * (NOUT * ES) + cbase : kOOB;
+                uint4 v = *(const uint4*)(otile + p * C::OSTRIDE + oc * 16);
+                f32x2_t f[NP];
+                Pairs<T>::unpack(v, f);
+                if (a.skip) {
+                    f32x2_t kk[NP];
+                    Pairs<T>::unpack(buf_load16(skip_rsrc, off), kk);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) f[j] += kk[j];
+                    v = Pairs<T>::pack(f);
+                    Pairs<T>::unpack(v, f);  // statistics of the values as stored
+                }
+                buf_store16(out_rsrc, off, v);
+                const float msk = valid ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (!FULL) f[j] *= msk;
+                    st_s[j] += f[j];
+                    st_q[j] = fma2(f[j], f[j], st_q[j]);
                 }
             }
-            __syncthreads();
-            const int nparts = a.tiles_x * a.tiles_y * gridDim.z;
-            const int part = ((blockIdx.x % (a.tiles_x * a.tiles_y)) * gridDim.z + cls);
-            for (int i = tid; i < NB * 2; i += C::NTHREADS) {
-                float t = 0.f;
+        };
+        if (y0 + C::TH <= a.Hv && x0 + C::TW <= a.Wv) epi2(std::true_type()); else epi2(std::false_type());
+        DDIMX_STAMP_AT(6);
+        if (!C::SEPARATE_OUT && t + 1 < t_end) {
+            __syncthreads();  // barrier C: out tile fully read before the halo region is overwritten
+            DDIMX_STAMP_AT(7);
+            halo_commit(t + 1);
+            DDIMX_STAMP_AT(8);
+            __syncthreads();  // barrier D
+            DDIMX_STAMP_AT(9);
+        }
+    }
+
+    DDIMX_STAMP_FLUSH();
+    // ---- statistics: one partial per workgroup -----------------------------------------------------------------
+    if (a.stats) {  // uniform branch
+        float* const red = (float*)smem;
+        // lanes with equal oc inside a wave: xor-reduce over the pixel-slot bits of the lane id
 #pragma unroll
-                for (int w = 0; w < C::NWAVES; ++w) t += red[w * NB * 2 + i];
-                a.stats[(((size_t)bs * nparts + part) * NOUT + cout0) * 2 + i] = t;
+        for (int o = C::OLPP; o < 64; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                st_s[j].x += __shfl_xor(st_s[j].x, o, 64);
+                st_s[j].y += __shfl_xor(st_s[j].y, o, 64);
+                st_q[j].x += __shfl_xor(st_q[j].x, o, 64);
+                st_q[j].y += __shfl_xor(st_q[j].y, o, 64);
             }
+        }
+        __syncthreads();  // everyone is done with wbuf / halo / out tile
+        if (lane < C::OLPP && ovalid) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                red[(wave * NB + oc * EPB + 2 * j) * 2 + 0] = st_s[j].x;
+                red[(wave * NB + oc * EPB + 2 * j) * 2 + 1] = st_q[j].x;
+                red[(wave * NB + oc * EPB + 2 * j + 1) * 2 + 0] = st_s[j].y;
+                red[(wave * NB + oc * EPB + 2 * j + 1) * 2 + 1] = st_q[j].y;
+            }
+        }
+        __syncthreads();
+        const int nparts = a.wgs_per_sample * gridDim.z;
+        const int part = wg * gridDim.z + cls;
+        for (int i = tid; i < NB * 2; i += C::NTHREADS) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::NWAVES; ++w) t += red[w * NB * 2 + i];
+            a.stats[(((size_t)bs * nparts + part) * NOUT + cout0) * 2 + i] = t;
         }
     }
 }
 
-#undef W_LOAD
-#undef W_STORE
 
 template <class C>
 hipError_t launch_conv_cfg(const ConvArgs& a, hipStream_t stream) {
@@ -381,19 +618,21 @@ hipError_t launch_conv_cfg(const ConvArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid(a.tiles_x * a.tiles_y * a.B, C::NOUT / C::NB, C::MODE == UP4 ? 2 : 1);
+    dim3 grid(a.wgs_per_sample * a.B, C::NOUT / C::NB, C::MODE == UP4 ? 2 : 1);
     hipLaunchKernelGGL(conv_mfma_kernel<C>, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
 // Host-side description of one configuration (tile geometry the caller needs for grids and slabs).
 struct ConvGeom {
-    int th, tw, nb, nout, classes;
+    int th, tw, nb, nout, classes, lds_bytes, nthreads;
 };
 
 // Implemented in conv_inst_*.hip: fills geometry / launches for (dtype, mode, cin, cout).
 // ``cout`` is the real output channel count (UP4: Cprev); returns hipErrorInvalidValue if unsupported.
-hipError_t conv_geometry(int dtype, int mode, int cin, int cout, ConvGeom* g);
-hipError_t conv_launch(int dtype, int mode, int cin, int cout, ConvArgs& a, hipStream_t stream);
+hipError_t conv_geometry(int dtype, int mode, int cin, int cout, int var, ConvGeom* g);
+hipError_t conv_launch(int dtype, int mode, int cin, int cout, int var, ConvArgs& a, hipStream_t stream);
+// variant choice for a problem size: the small-tile variant when the large one gives < 200 workgroups
+int conv_pick_variant(int dtype, int mode, int cin, int cout, int B, int Hv, int Wv);
 
 }  // namespace ddimx

@@ -1,0 +1,189 @@
+// "NT" GEMM for the FNet bottleneck:  C[z][M][N] (+)= A[z][M][K] * B[z][N][K]^T  (+bias) (gelu_new) (+resid)
+// Both operands are K-contiguous fp32 in memory (torch Linear weights [N][K], token matrices [M][K],
+// DFT-as-GEMM factors).  Two MFMA paths share the structure (64x64 workgroup tile, 4 waves 2x2 of one
+// 32x32 tile, register-staged double-buffered LDS):
+//   PREC_F32  : v_mfma_f32_32x32x2_f32, exact fp32 FMA chain (parity mode, and always for the DFT factors)
+//   PREC_BF16 : operands rounded to bf16 while they are staged into LDS, v_mfma_f32_32x32x16_bf16 with
+//               fp32 accumulation (performance mode, dense-weight GEMMs only)
+// Skinny shapes (M = B*S is small) are split along K over blockIdx.z; partial tiles go to a workspace and a
+// second kernel sums them in a fixed order and applies the epilogue (deterministic, no atomics).
+#include "kernels.h"
+
+namespace ddimx {
+
+constexpr int GBM = 64, GBN = 64;
+
+template <int PREC> struct GemmTraits;
+template <> struct GemmTraits<0> {  // fp32
+    static constexpr int BK = 32, ROWB = BK * 4 + 16;  // 144 B = 9 slots (odd)
+};
+template <> struct GemmTraits<1> {  // bf16
+    static constexpr int BK = 64, ROWB = BK * 2 + 16;  // 144 B
+};
+
+__device__ __forceinline__ float4 gemm_ld4(const float* base, int row, int rows, int k, int kend, int ld, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows) {
+        const float* p = base + (size_t)row * ld + k;
+        if (vec && k + 3 < kend) {
+            v = *(const float4*)p;
+        } else {
+            if (k < kend) v.x = p[0];
+            if (k + 1 < kend) v.y = p[1];
+            if (k + 2 < kend) v.z = p[2];
+            if (k + 3 < kend) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs g) {
+    typedef GemmTraits<PREC> TR;
+    constexpr int BK = TR::BK, ROWB = TR::ROWB;
+    constexpr int F4 = BK / 4;          // float4 loads per row per chunk
+    constexpr int LPT = GBM * F4 / 256;  // float4 loads per thread per operand (2 for fp32, 4 for bf16)
+    __shared__ __attribute__((aligned(16))) char sA[2][GBM * ROWB];
+    __shared__ __attribute__((aligned(16))) char sB[2][GBN * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int z = blockIdx.z / g.splitk, ks = blockIdx.z % g.splitk;
+    const float* A = g.A + (size_t)z * g.sA;
+    const float* B = g.B + (size_t)z * g.sB;
+    const bool va = (g.lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
+    const bool vb = (g.ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    // this block's K range (whole chunks)
+    const int nchunks_all = (g.K + BK - 1) / BK;
+    const int cper = (nchunks_all + g.splitk - 1) / g.splitk;
+    const int c0 = ks * cper;
+    const int c1 = (c0 + cper < nchunks_all) ? c0 + cper : nchunks_all;
+    const int nk = c1 - c0;
+
+    float4 ra[LPT], rb[LPT];
+    auto load = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
+            ra[i] = gemm_ld4(A, m0 + row, g.M, k0 + kq, g.K, g.lda, va);
+            rb[i] = gemm_ld4(B, n0 + row, g.N, k0 + kq, g.K, g.ldb, vb);
+        }
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
+            if constexpr (PREC == 0) {
+                *(float4*)(sA[buf] + row * ROWB + kq * 4) = ra[i];
+                *(float4*)(sB[buf] + row * ROWB + kq * 4) = rb[i];
+            } else {
+                *(uint2*)(sA[buf] + row * ROWB + kq * 2) =
+                    make_uint2(Piece<__bf16>::pk(ra[i].x, ra[i].y), Piece<__bf16>::pk(ra[i].z, ra[i].w));
+                *(uint2*)(sB[buf] + row * ROWB + kq * 2) =
+                    make_uint2(Piece<__bf16>::pk(rb[i].x, rb[i].y), Piece<__bf16>::pk(rb[i].z, rb[i].w));
+            }
+        }
+    };
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (nk > 0) {
+        load(c0 * BK);
+        store(0);
+    }
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 1 < nk) load((c0 + kc + 1) * BK);
+        const char* pa = sA[kc & 1] + (wm * 32 + l31) * ROWB + h * 16;
+        const char* pb = sB[kc & 1] + (wn * 32 + l31) * ROWB + h * 16;
+#pragma unroll
+        for (int kg = 0; kg < (BK * (PREC ? 2 : 4)) / 32; ++kg) {  // 32-byte k-groups
+            const uint4 a = *(const uint4*)(pa + kg * 32);
+            const uint4 b = *(const uint4*)(pb + kg * 32);
+            if constexpr (PREC == 0) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                              __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nk) store((kc + 1) & 1);
+        __syncthreads();
+    }
+    // D[row m][col n]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int n = n0 + wn * 32 + l31;
+    if (n >= g.N) return;
+    if (g.splitk > 1) {
+        float* P = g.partial + ((size_t)(z * g.splitk + ks) * g.M) * g.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < g.M) P[(size_t)m * g.N + n] = acc[r];
+        }
+        return;
+    }
+    float* C = g.C + (size_t)z * g.sC;
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.M) {
+            const size_t o = (size_t)m * g.ldc + n;
+            float v = acc[r];
+            if (g.accumulate) v += C[o];
+            v += bv;
+            if (g.act == 1) v = gelu_new_f(v);
+            if (g.resid) v += g.resid[(size_t)z * g.sC + o];
+            C[o] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmArgs g) {
+    const long long total = (long long)g.batch * g.M * g.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = i % g.N;
+        const long long mz = i / g.N;
+        const int m = mz % g.M, z = mz / g.M;
+        float v = 0.f;
+        for (int s = 0; s < g.splitk; ++s) v += g.partial[((size_t)(z * g.splitk + s) * g.M + m) * g.N + n];
+        const size_t o = (size_t)z * g.sC + (size_t)m * g.ldc + n;
+        if (g.accumulate) v += g.C[o];
+        if (g.bias) v += g.bias[n];
+        if (g.act == 1) v = gelu_new_f(v);
+        if (g.resid) v += g.resid[o];
+        g.C[o] = v;
+    }
+}
+
+int gemm_pick_splitk(int M, int N, int K, int batch, int bf16) {
+    const int bk = bf16 ? 64 : 32;
+    const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) * (batch > 0 ? batch : 1);
+    const int chunks = (K + bk - 1) / bk;
+    int s = 1;
+    while (s < 8 && tiles * s * 2 <= 512 && chunks / (s * 2) >= 2) s *= 2;
+    return s;
+}
+
+hipError_t gemm_launch(GemmArgs g, hipStream_t s) {
+    if (g.batch < 1) g.batch = 1;
+    if (g.splitk < 1 || !g.partial) g.splitk = 1;
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.batch * g.splitk);
+    if (g.bf16)
+        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), 0, s, g);
+    if (g.splitk > 1) {
+        const long long total = (long long)g.batch * g.M * g.N;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ddimx

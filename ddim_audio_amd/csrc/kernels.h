@@ -1,4 +1,4 @@
-// Launch wrappers of the non-MFMA kernels (kernels.hip) and the fp32 MFMA GEMM (gemm_f32.hip).
+// Launch wrappers of the non-MFMA kernels (kernels.hip) and the MFMA GEMM (gemm.hip).
 // All enqueue on the given stream, never allocate or synchronise (graph-capturable).
 #pragma once
 #include "common.h"
@@ -11,7 +11,7 @@ hipError_t conv_in_launch(int dtype, const float* x, const float* w /*[C0][cin][
                           float* stats, int B, int cin, int C0, int H, int W, hipStream_t s);
 int conv_in_nparts(int H, int W);
 // out-conv: models/diffusion.py:199-208 preceded by x + hidden[0] (:284).  (a + b) NHWC T -> eps [B][cout][H][W] fp32
-hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float* w /*[cout][C0][3][3]*/,
+hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float* w /*packed [9][cout][C0] fp32*/,
                            const float* bias, float* out, int B, int C0, int cout, int H, int W, hipStream_t s);
 
 // ---- GroupNorm statistics -> folded per-(sample, channel) scale / shift ---------------------------
@@ -40,18 +40,22 @@ hipError_t linear_rows_launch(const float* x, const int64_t* idx, const float* W
 hipError_t layernorm_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma,
                             const float* beta, float eps, float* y, int M, int N, hipStream_t s);
 
-// ---- fp32 GEMM on v_mfma_f32_32x32x2_f32: C[z][M][N] (+)= A[z][M][K] * B[z][N][K]^T ----------------------
+// ---- "NT" GEMM (gemm.hip): C[z][M][N] (+)= A[z][M][K] * B[z][N][K]^T; fp32 or bf16 MFMA, optional split-K ----
 struct GemmArgs {
     const float* A; const float* B; float* C;
     const float* bias;      // [N] or null
-    const float* resid;     // [M][N] (ldc) added in the epilogue, or null
+    const float* resid;     // same layout as C, added in the epilogue, or null
+    float* partial;         // split-K workspace [batch*splitk][M][N] (required when splitk > 1)
     int M, N, K, lda, ldb, ldc;
-    long long sA, sB, sC;   // batch strides (elements); batch = grid.z
+    long long sA, sB, sC;   // batch strides (elements)
     int batch;
+    int splitk;             // K split over blockIdx.z (1 = none)
     int accumulate;         // C += ...
     int act;                // 0 none, 1 gelu_new
+    int bf16;               // 1: round operands to bf16 while staging, v_mfma_f32_32x32x16_bf16
 };
-hipError_t gemm_f32_launch(const GemmArgs& g, hipStream_t s);
+hipError_t gemm_launch(GemmArgs g, hipStream_t s);
+int gemm_pick_splitk(int M, int N, int K, int batch, int bf16);
 
 // ---- sampler / training elementwise ------------------------------------------------------------------
 // coef rows: (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1) fp32; step is a device counter

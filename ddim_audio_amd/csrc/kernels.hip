@@ -77,12 +77,77 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
     }
 }
 
+
+// ---- fast path (C0 = 32, cin = 2): one lane = one pixel x all 32 output channels.  Input reads are
+// coalesced along W, the 576 weights are wave-uniform (scalar loads), each lane stores 64 contiguous bytes.
+template <typename T, int C0, int CIN>
+__global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ out,
+                                                           float* __restrict__ stats, int H, int W) {
+    constexpr int EPB = Piece<T>::N;
+    __shared__ float red[4][C0 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const int HW = H * W;
+    const float* xb = x + (size_t)b * CIN * HW;
+    float s[C0], q[C0];
+#pragma unroll
+    for (int c = 0; c < C0; ++c) s[c] = q[c] = 0.f;
+    for (int it = 0; it < kInPixPerBlock / 256; ++it) {
+        const int pix = part * kInPixPerBlock + it * 256 + tid;
+        if (pix >= HW) break;
+        const int py = pix / W, px = pix % W;
+        float v[CIN * 9];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int gy = py + k / 3 - 1, gx = px + k % 3 - 1;
+                v[ci * 9 + k] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)ci * HW + (size_t)gy * W + gx] : 0.f;
+            }
+        T* op = out + ((size_t)b * HW + pix) * C0;
+#pragma unroll
+        for (int c0 = 0; c0 < C0; c0 += EPB) {
+            float acc[EPB];
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) {
+                float a = bias[c0 + j];
+#pragma unroll
+                for (int r = 0; r < CIN * 9; ++r) a = fmaf(v[r], w[(c0 + j) * CIN * 9 + r], a);
+                acc[j] = a;
+            }
+            const uint4 pv = Piece<T>::pack(acc);
+            Piece<T>::unpack(pv, acc);
+            *(uint4*)(op + c0) = pv;
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) { s[c0 + j] += acc[j]; q[c0 + j] = fmaf(acc[j], acc[j], q[c0 + j]); }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int c = 0; c < C0; ++c) {
+            const float ts = wave_sum(s[c]), tq = wave_sum(q[c]);
+            if (lane == 0) { red[wave][c * 2] = ts; red[wave][c * 2 + 1] = tq; }
+        }
+        __syncthreads();
+        if (tid < C0 * 2)
+            stats[(((size_t)b * gridDim.x + part) * C0) * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
 hipError_t conv_in_launch(int dtype, const float* x, const float* w, const float* bias, void* out, float* stats, int B,
                           int cin, int C0, int H, int W, hipStream_t s) {
     const int epb = dtype == DT_BF16 ? 8 : 4;
     const int opp = C0 / epb;
     if (C0 % epb || opp > 64 || (opp & (opp - 1))) return hipErrorInvalidValue;
     dim3 grid(conv_in_nparts(H, W), B);
+    if (C0 == 32 && cin == 2) {
+        if (dtype == DT_BF16)
+            hipLaunchKernelGGL((conv_in_fast_kernel<__bf16, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (__bf16*)out, stats, H, W);
+        else
+            hipLaunchKernelGGL((conv_in_fast_kernel<float, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (float*)out, stats, H, W);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(cin * 9 * C0 + 4 * C0 * 2) * 4;
     if (dtype == DT_BF16)
         hipLaunchKernelGGL(conv_in_kernel<__bf16>, grid, dim3(256), lds, s, x, w, bias, (__bf16*)out, stats, cin, C0, H, W);
@@ -136,7 +201,7 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const T* __restrict__ a, 
             const float v = tile[((py + k / 3) * IW + px + k % 3) * LS + ci];
 #pragma unroll
             for (int o = 0; o < 4; ++o)
-                if (o < cout) acc[o] = fmaf(v, w[((size_t)o * C0 + ci) * 9 + k], acc[o]);
+                if (o < cout) acc[o] = fmaf(v, w[((size_t)k * cout + o) * C0 + ci], acc[o]);
         }
     }
     const int gy = y0 + py, gx = x0 + px;
@@ -147,6 +212,62 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const T* __restrict__ a, 
     }
 }
 
+
+// ---- fast path (C0 = 32, cout = 2): (a + b) staged once per tile into LDS in the activation dtype with a
+// pixel stride of C0*es+16 bytes (conflict-free b128 reads), one lane = one output pixel, weights wave-uniform.
+template <typename T, int C0, int COUT>
+__global__ void __launch_bounds__(256) conv_out_fast_kernel(const T* __restrict__ a, const T* __restrict__ b2,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int H, int W, int tiles_x,
+                                                            int tiles_y) {
+    constexpr int EPB = Piece<T>::N, ES = sizeof(T);
+    constexpr int IH = kOutTH + 2, IW = kOutTW + 2;
+    constexpr int CPP = C0 / EPB, PS = C0 * ES + 16;
+    __shared__ __attribute__((aligned(16))) char tile[IH * IW * PS];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = ty * kOutTH, x0 = tx * kOutTW;
+    for (int i = tid; i < IH * IW * CPP; i += 256) {
+        const int c = i % CPP, pix = i / CPP;
+        const int gy = y0 - 1 + pix / IW, gx = x0 - 1 + pix % IW;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t g = (((size_t)b * H + gy) * W + gx) * C0 + c * EPB;
+            float f[EPB], k[EPB];
+            Piece<T>::unpack(*(const uint4*)(a + g), f);
+            Piece<T>::unpack(*(const uint4*)(b2 + g), k);
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) f[j] += k[j];
+            v = Piece<T>::pack(f);
+        }
+        *(uint4*)(tile + pix * PS + c * 16) = v;
+    }
+    __syncthreads();
+    const int py = tid / kOutTW, px = tid % kOutTW;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) {  // w: [tap][cout][cin], 64 contiguous wave-uniform floats per tap
+        const char* tp = tile + ((py + k / 3) * IW + px + k % 3) * PS;
+        const float* wk = w + k * COUT * C0;
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) {
+            float f[EPB];
+            Piece<T>::unpack(*(const uint4*)(tp + c * 16), f);
+#pragma unroll
+            for (int j = 0; j < EPB; ++j)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] = fmaf(f[j], wk[o * C0 + c * EPB + j], acc[o]);
+        }
+    }
+    const int gy = y0 + py, gx = x0 + px;
+    if (gy < H && gx < W) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) out[(((size_t)b * COUT + o) * H + gy) * W + gx] = acc[o];
+    }
+}
+
 hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float* w, const float* bias, float* out, int B,
                            int C0, int cout, int H, int W, hipStream_t s) {
     if (cout > 4 || C0 % 8) return hipErrorInvalidValue;
@@ -154,6 +275,15 @@ hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float*
     const size_t lds = (size_t)(kOutTH + 2) * (kOutTW + 2) * (C0 + 1) * 4;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     dim3 grid(tiles_x * tiles_y * B);
+    if (C0 == 32 && cout == 2) {
+        if (dtype == DT_BF16)
+            hipLaunchKernelGGL((conv_out_fast_kernel<__bf16, 32, 2>), grid, dim3(256), 0, s, (const __bf16*)a, (const __bf16*)b,
+                               w, bias, out, H, W, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL((conv_out_fast_kernel<float, 32, 2>), grid, dim3(256), 0, s, (const float*)a, (const float*)b, w,
+                               bias, out, H, W, tiles_x, tiles_y);
+        return hipGetLastError();
+    }
     if (dtype == DT_BF16)
         hipLaunchKernelGGL(conv_out_kernel<__bf16>, grid, dim3(256), lds, s, (const __bf16*)a, (const __bf16*)b, w, bias,
                            out, C0, cout, H, W, tiles_x, tiles_y);

@@ -114,6 +114,11 @@ int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const floa
                       int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                       float* stats, int B, int H, int W, void* stream);
 long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W);
+/* Diagnostic only: as ddimx_conv3x3_fwd (xf = 2, act = 1); in a -DDDIMX_STAMP build of the library the kernel
+ * also writes per-wave per-phase cycle sums to stamps[waves][12] (tools/conv_stamps.py). */
+int ddimx_debug_conv3x3_stamps(int dtype, int C, const void* x, const void* w, const float* chan_add,
+                                const float* in_scale, const float* in_shift, void* y, float* stats,
+                                unsigned long long* stamps, int B, int H, int W, void* stream);
 /* y = x + (h * scale + shift): tail of Residual_Block (models/diffusion.py:54-56), NHWC, stats nullable */
 int ddimx_resid_gn_fwd(int dtype, int C, const void* x, const void* h, const float* scale, const float* shift, void* y,
                        float* stats, int B, int H, int W, void* stream);

@@ -1,0 +1,30 @@
+"""Run one level's fused 3x3 conv repeatedly (for rocprofv3 --pmc runs).  usage: conv_one.py LEVEL [B] [REPS]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ddim_audio_amd import _lib  # noqa: E402
+
+lvl = int(sys.argv[1])
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+lib = _lib.load()
+dt, tdt = _lib.DDIMX_BF16, torch.bfloat16
+dev = torch.device("cuda", 0)
+C = [32, 64, 96, 128, 192, 256][lvl]
+H, W = 1024 >> lvl, 256 >> lvl
+x = torch.randn(B, H, W, C, device=dev).to(tdt)
+y = torch.empty_like(x)
+w = (torch.randn(9 * C * C, device=dev) * (1.0 / (9 * C) ** 0.5)).to(tdt)
+temb = torch.randn(B, C, device=dev) * 0.1
+scale = torch.rand(B, C, device=dev) + 0.5
+shift = torch.randn(B, C, device=dev) * 0.1
+stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)), device=dev)
+for _ in range(reps):
+    _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale), _lib.ptr(shift), 2, 1,
+                                     _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+torch.cuda.synchronize()
+print("done", float(y.float().abs().mean()))
