@@ -450,19 +450,24 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     float* other = w.Y;
     for (int i = 0; i < f.fnet_layers; ++i) {
         const ddimx_ctx::FL& L = c->fl[i];
-        // Ut[b] = [C_H; S_H] * X[b]^T   -> [2*hid][S]
+        // Ut[b] = D_H * X[b]^T -> [2*hid][S]; D_H rows interleaved (2k: cos_k, 2k+1: sin_k), so that row pair k of
+        // Ut[b] is one contiguous K-vector [cos-part(S) | sin-part(S)] for the sequence transform
         CHK(fnet_gemm(w, s, tb->dft_hidden, cur, w.Ut, 2 * hid, S, hid, hid, hid, S, nullptr, nullptr, 0, 0, 0, B, 0,
                       (long long)S * hid, (long long)2 * hid * S));
-        // Z[b] = C_S * Utc[b]^T ; Z[b] += (-S_S) * Uts[b]^T + X[b]   (Re(FFT2) + residual)
-        CHK(fnet_gemm(w, s, tb->dft_seq, w.Ut, w.Z, S, hid, S, S, S, hid, nullptr, nullptr, 0, 0, 0, B, 0,
+        // Z[b] = [C_S | -S_S] * Ut[b]^T + X[b]   (Re(FFT2) + residual) in one GEMM with K = 2S
+        CHK(fnet_gemm(w, s, tb->dft_seq, w.Ut, w.Z, S, hid, 2 * S, 2 * S, 2 * S, hid, nullptr, cur, 0, 0, 0, B, 0,
                       (long long)2 * hid * S, (long long)S * hid));
-        CHK(fnet_gemm(w, s, tb->dft_seq + (size_t)S * S, w.Ut + (size_t)hid * S, w.Z, S, hid, S, S, S, hid, nullptr, cur, 0, 1,
-                      0, B, 0, (long long)2 * hid * S, (long long)S * hid));
         HIPCHK(layernorm_launch(DT_F32, w.Z, nullptr, 1, pf(c, packed, L.ln1_w), pf(c, packed, L.ln1_b), eps, other, M, hid, s));
-        // FFN
+        // FFN; the second GEMM's split-K reduce also applies bias, residual and output.LayerNorm
         CHK(fnet_gemm(w, s, other, pf(c, packed, L.w1), w.Hb, M, inter, hid, hid, hid, inter, pf(c, packed, L.b1), nullptr, 1, 0, bf));
-        CHK(fnet_gemm(w, s, w.Hb, pf(c, packed, L.w2), w.Z, M, hid, inter, inter, inter, hid, pf(c, packed, L.b2), other, 0, 0, bf));
-        HIPCHK(layernorm_launch(DT_F32, w.Z, nullptr, 1, pf(c, packed, L.ln2_w), pf(c, packed, L.ln2_b), eps, cur, M, hid, s));
+        {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A = w.Hb; g.B = pf(c, packed, L.w2); g.C = w.Z; g.bias = pf(c, packed, L.b2); g.resid = other; g.partial = w.gpart;
+            g.M = M; g.N = hid; g.K = inter; g.lda = inter; g.ldb = inter; g.ldc = hid; g.batch = 1; g.bf16 = bf;
+            g.splitk = gemm_pick_splitk(M, hid, inter, 1, bf);
+            HIPCHK(gemm_ln_launch(g, pf(c, packed, L.ln2_w), pf(c, packed, L.ln2_b), eps, cur, s));
+        }
     }
     CHK(fnet_gemm(w, s, cur, pf(c, packed, c->cout_w), w.O, M, width, hid, hid, hid, width, pf(c, packed, c->cout_b), nullptr,
                   0, 0, bf));

@@ -523,8 +523,9 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
         // ---- epilogue 2: coalesced stores of whole pixel rows, + skip, per-channel statistics --------------
         // FULL tiles (entirely inside the image) need no per-lane validity; ragged ones drop stores through the
         // buffer bounds check and mask their statistics.
-        auto epi2 = [&](auto full_tag) __attribute__((always_inline)) {
+        auto epi2 = [&](auto full_tag, auto skip_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
+            constexpr bool SKIP = decltype(skip_tag)::value;
             constexpr int STEP = C::NTHREADS / C::OLPP;          // pixels per pass
             constexpr int NPASS = (C::P + STEP - 1) / STEP;
             if (!ovalid) return;
@@ -541,7 +542,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
                 uint4 v = *(const uint4*)(otile + p * C::OSTRIDE + oc * 16);
                 f32x2_t f[NP];
                 Pairs<T>::unpack(v, f);
-                if (a.skip) {
+                if (SKIP) {
                     f32x2_t kk[NP];
                     Pairs<T>::unpack(buf_load16(skip_rsrc, off), kk);
 #pragma unroll
@@ -559,7 +560,11 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
                 }
             }
         };
-        if (y0 + C::TH <= a.Hv && x0 + C::TW <= a.Wv) epi2(std::true_type()); else epi2(std::false_type());
+        {
+            const bool full = y0 + C::TH <= a.Hv && x0 + C::TW <= a.Wv;  // wave-uniform
+            if (a.skip) { if (full) epi2(std::true_type(), std::true_type()); else epi2(std::false_type(), std::true_type()); }
+            else { if (full) epi2(std::true_type(), std::false_type()); else epi2(std::false_type(), std::false_type()); }
+        }
         DDIMX_STAMP_AT(6);
         if (!C::SEPARATE_OUT && t + 1 < t_end) {
             __syncthreads();  // barrier C: out tile fully read before the halo region is overwritten

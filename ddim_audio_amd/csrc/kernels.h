@@ -56,6 +56,8 @@ struct GemmArgs {
 };
 hipError_t gemm_launch(GemmArgs g, hipStream_t s);
 int gemm_pick_splitk(int M, int N, int K, int batch, int bf16);
+// out = LayerNorm(A*B^T + bias + resid) * gamma + beta (rows of N <= 2048), GEMM via the partial workspace
+hipError_t gemm_ln_launch(GemmArgs g, const float* gamma, const float* beta, float eps, float* out, hipStream_t s);
 
 // ---- sampler / training elementwise ------------------------------------------------------------------
 // coef rows: (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1) fp32; step is a device counter

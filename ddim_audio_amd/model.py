@@ -311,8 +311,8 @@ class Model(_Node):
             ch, sh = _dft_tables(hid)
             cs, ss = _dft_tables(s)
             import numpy as np
-            dh = torch.from_numpy(np.concatenate([ch, sh], axis=0)).to(device)
-            ds = torch.from_numpy(np.stack([cs, -ss], axis=0)).to(device)
+            dh = torch.from_numpy(np.stack([ch, sh], axis=1).reshape(2 * hid, hid)).to(device)  # rows 2k: cos_k, 2k+1: sin_k
+            ds = torch.from_numpy(np.concatenate([cs, -ss], axis=1)).contiguous().to(device)      # [S][2S] = [cos | -sin]
             self._tables = {key: (pe, dh, ds)}  # keep only the latest T
         return self._tables[key]
 

@@ -50,8 +50,8 @@ typedef struct {
 
 /* Host-built constant tables for a given T (device pointers, fp32):
  *   posenc     [S][width]    Add_Encoding table (models/diffusion.py:81-92,131-140) in NHWC token order
- *   dft_hidden [2*hid][hid]  rows 0..hid-1 = cos(2 pi k n / hid), rows hid.. = sin(...)
- *   dft_seq    [2][S][S]     cos(2 pi k n / S) and -sin(2 pi k n / S)
+ *   dft_hidden [2*hid][hid]  interleaved rows: 2k = cos(2 pi k n / hid), 2k+1 = sin(2 pi k n / hid)
+ *   dft_seq    [S][2*S]      row k = [cos(2 pi k n / S), n < S | -sin(2 pi k n / S), n < S]
  * with S = T / 2^(n_levels-1), width = ch[-1] * f_size / 2^(n_levels-1). */
 typedef struct {
     const float* posenc;
