@@ -531,27 +531,37 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
             if (!ovalid) return;
             const unsigned rowb = (unsigned)(a.Wv * NOUT * ES);  // bytes per virtual output row
             const unsigned cbase = (unsigned)((cout0 + oc * EPB) * ES);
+            // pass 1: offsets, and ALL skip loads of the tile in flight before the first store (vmcnt is in-order
+            // and counts stores: a load issued behind a store would wait for that store to complete)
+            unsigned offs[NPASS];
+            uint4 skv[SKIP ? NPASS : 1];
+            bool vld[NPASS];
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 const int p = oslot + k * STEP;                  // TW is a power of two: shifts and masks
-                if (C::P % STEP != 0 && p >= C::P) break;
                 const int vy = y0 + p / C::TW, vx = x0 + p % C::TW;
-                const bool valid = FULL || (vy < a.Hv && vx < a.Wv);
+                vld[k] = (C::P % STEP == 0 || p < C::P) && (FULL || (vy < a.Hv && vx < a.Wv));
                 const unsigned oy = (C::MODE == UP4) ? 2u * vy + cls : (unsigned)vy;
-                const unsigned off = valid ? oy * rowb + (unsigned)vx * (NOUT * ES) + cbase : kOOB;
+                offs[k] = vld[k] ? oy * rowb + (unsigned)vx * (NOUT * ES) + cbase : kOOB;
+                if (SKIP) skv[k] = buf_load16(skip_rsrc, offs[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int p = oslot + k * STEP;
+                if (C::P % STEP != 0 && p >= C::P) break;
                 uint4 v = *(const uint4*)(otile + p * C::OSTRIDE + oc * 16);
                 f32x2_t f[NP];
                 Pairs<T>::unpack(v, f);
                 if (SKIP) {
                     f32x2_t kk[NP];
-                    Pairs<T>::unpack(buf_load16(skip_rsrc, off), kk);
+                    Pairs<T>::unpack(skv[k], kk);
 #pragma unroll
                     for (int j = 0; j < NP; ++j) f[j] += kk[j];
                     v = Pairs<T>::pack(f);
                     Pairs<T>::unpack(v, f);  // statistics of the values as stored
                 }
-                buf_store16(out_rsrc, off, v);
-                const float msk = valid ? 1.f : 0.f;
+                buf_store16(out_rsrc, offs[k], v);
+                const float msk = vld[k] ? 1.f : 0.f;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     if (!FULL) f[j] *= msk;
