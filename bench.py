@@ -70,16 +70,20 @@ def per_kernel_times(model, B, T, reps=20):
         stats = torch.empty(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)) + 2 * B * C * 4096, device=dev)
         st = _lib.stream()
 
-        def conv():
+        def conv():  # K1 of the block: GroupNorm affine + SiLU prologue, + timestep embedding, SiLU
             _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale),
                                              _lib.ptr(shift), 2, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+
+        def conv2():  # K2 of the block: GroupNorm affine prologue, + bias, SiLU
+            _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), None, 0, _lib.ptr(scale),
+                                             _lib.ptr(shift), 1, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
 
         def resid():
             _lib.check(lib.ddimx_resid_gn_fwd(dt, C, _lib.ptr(x), _lib.ptr(h), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
                                               _lib.ptr(stats), B, H, W, st))
 
         elems = B * H * W * C
-        tc, tr = timed(conv), timed(resid)
+        tc, tr = 0.5 * (timed(conv) + timed(conv2)), timed(resid)
         rows.append(dict(kernel=f"conv_mfma_kernel<{'bf16' if bf16 else 'f32'},C={C},3x3>", level=lvl, launches_per_fwd=4 * res,
                          seconds=tc, alg_bytes=2 * elems * es + 9 * C * C * es, flops=2.0 * elems * 9 * C))
         rows.append(dict(kernel=f"resid_kernel<{'bf16' if bf16 else 'f32'},C={C}>", level=lvl, launches_per_fwd=2 * res,
@@ -99,7 +103,8 @@ def cpu_baseline(T, iters=3, batch=2):
     synth.fill_state_dict(sd)
     sd["temb.te"] = ref_cpu.timestep_table(cfg.diffusion.num_diffusion_timesteps)
     alphas = schedule.make_schedule(cfg.diffusion)[1]
-    cores = torch.get_num_threads()
+    cores = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
+    torch.set_num_threads(cores)
     fn = lambda a, b: ref_cpu.model_forward(sd, cfg, a, b)  # noqa: E731
     with torch.no_grad():
         ref_cpu.model_forward(sd, cfg, torch.randn(1, 2, 64, 256), torch.tensor([10]))  # warm-up
@@ -219,6 +224,11 @@ def main():
             else:
                 out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                                    "frac": dom["tflops"] / MFMA_BF16_PEAK_TF, "traffic": None}
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+            if os.path.exists(tpath):
+                tr = json.load(open(tpath))
+                if tr.get("kernel") == dom["kernel"] and tr.get("batch") == B and tr.get("t_size") == T:
+                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             out["roofline"].update(kernel=dom["kernel"], launch_us=dom["seconds"] * 1e6, alg_bytes_per_launch=dom["alg_bytes"],
                                    launches_per_fwd=dom["launches_per_fwd"])
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
