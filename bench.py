@@ -134,12 +134,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_idx = local_rank % max(ndev, 1)  # one rank per GPU; (rehearsals on a 1-GPU box put every rank on cuda:0)
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device("cuda", dev_idx)
     import torch.distributed as dist
+    backend = os.environ.get("DDIMX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" for rehearsals
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import numpy as np
     import ddim_audio_amd as D
@@ -179,7 +185,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    et = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
     elapsed = float(et.item())
