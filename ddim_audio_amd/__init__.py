@@ -13,9 +13,9 @@ def __getattr__(name):
     if name == "Model":
         from .model import Model
         return Model
-    if name == "generalized_steps":
-        from .sampler import generalized_steps
-        return generalized_steps
+    if name in ("generalized_steps", "ddpm_steps"):
+        from . import sampler
+        return getattr(sampler, name)
     if name in ("noise_estimation_loss", "loss_registry"):
         from . import losses
         return getattr(losses, name)

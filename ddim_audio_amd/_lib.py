@@ -55,7 +55,9 @@ _SIGS = {
                                        c_int, c_int, c_void_p]),
     "ddimx_temb_fwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_step_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ddimx_step_begin_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "ddimx_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
+    "ddimx_ddpm_update": (c_int, [c_void_p] * 7 + [c_longlong, c_void_p]),
     "ddimx_step_end": (c_int, [c_void_p, c_void_p]),
     "ddimx_qsample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     "ddimx_sqerr_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),

@@ -688,12 +688,21 @@ int ddimx_temb_fwd(const float* te, const int64_t* t, const float* w0, const flo
 }
 
 int ddimx_step_begin(const float* coef, const int* step, int64_t* t, int B, void* stream) {
-    HIPCHK(step_begin_launch(coef, step, t, B, (hipStream_t)stream));
+    HIPCHK(step_begin_launch(coef, step, t, B, 6, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_step_begin_ex(const float* coef, int row_stride, const int* step, int64_t* t, int B, void* stream) {
+    HIPCHK(step_begin_launch(coef, step, t, B, row_stride, (hipStream_t)stream));
     return 0;
 }
 int ddimx_ddim_update(float* xt, const float* et, const float* noise, float* x0, const float* coef, const int* step,
                       long long n, void* stream) {
     HIPCHK(ddim_update_launch(xt, et, noise, x0, coef, step, n, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_ddpm_update(const float* x, const float* et, const float* noise, float* x0, float* xn, const float* coef,
+                      const int* step, long long n, void* stream) {
+    HIPCHK(ddpm_update_launch(x, et, noise, x0, xn, coef, step, n, (hipStream_t)stream));
     return 0;
 }
 int ddimx_step_end(int* step, void* stream) {

@@ -61,9 +61,11 @@ hipError_t gemm_ln_launch(GemmArgs g, const float* gamma, const float* beta, flo
 
 // ---- sampler / training elementwise ------------------------------------------------------------------
 // coef rows: (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1) fp32; step is a device counter
-hipError_t step_begin_launch(const float* coef, const int* step, int64_t* t, int B, hipStream_t s);
+hipError_t step_begin_launch(const float* coef, const int* step, int64_t* t, int B, int stride, hipStream_t s);
 hipError_t step_end_launch(int* step, hipStream_t s);
 hipError_t ddim_update_launch(float* xt, const float* et, const float* noise, float* x0, const float* coef,
+                              const int* step, long long n, hipStream_t s);
+hipError_t ddpm_update_launch(const float* x, const float* e, const float* noise, float* x0, float* xn, const float* coef,
                               const int* step, long long n, hipStream_t s);
 hipError_t qsample_launch(const float* x0, const float* e, const float* alphas, const int64_t* t, float* x, int B,
                           long long per, hipStream_t s);

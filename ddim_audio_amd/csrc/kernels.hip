@@ -617,14 +617,14 @@ hipError_t layernorm_launch(int x_dtype, const void* x, const float* add, int ad
 // device step counter, so a captured graph can be replayed for every step.
 // =====================================================================================================
 __global__ void step_begin_kernel(const float* __restrict__ coef, const int* __restrict__ step, int64_t* __restrict__ t,
-                                  int B) {
+                                  int B, int stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) t[i] = (int64_t)coef[(size_t)step[0] * 6];
+    if (i < B) t[i] = (int64_t)coef[(size_t)step[0] * stride];
 }
 __global__ void step_end_kernel(int* step) { step[0] += 1; }
 
-hipError_t step_begin_launch(const float* coef, const int* step, int64_t* t, int B, hipStream_t s) {
-    hipLaunchKernelGGL(step_begin_kernel, dim3((B + 63) / 64), dim3(64), 0, s, coef, step, t, B);
+hipError_t step_begin_launch(const float* coef, const int* step, int64_t* t, int B, int stride, hipStream_t s) {
+    hipLaunchKernelGGL(step_begin_kernel, dim3((B + 63) / 64), dim3(64), 0, s, coef, step, t, B, stride);
     return hipGetLastError();
 }
 hipError_t step_end_launch(int* step, hipStream_t s) {
@@ -667,6 +667,32 @@ hipError_t ddim_update_launch(float* xt, const float* et, const float* noise, fl
     const long long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(ddim_update_kernel, dim3(blocks), dim3(256), 0, s, xt, et, noise, x0, coef, step, n4);
+    return hipGetLastError();
+}
+
+
+// ---- ddpm_steps update (functions/denoising.py:72-90), one pass: coef row = (t, (1/at).sqrt(), (1/at-1).sqrt(),
+// atm1.sqrt()*beta_t, (1-beta_t).sqrt()*(1-atm1), 1-at, mask*exp(0.5*log(beta_t))) built on the host with the
+// reference's fp32 tensor arithmetic; every product/sum is rounded separately like the eager ops it replaces.
+__global__ void __launch_bounds__(256) ddpm_update_kernel(const float* __restrict__ x, const float* __restrict__ e,
+                                                          const float* __restrict__ noise, float* __restrict__ x0,
+                                                          float* __restrict__ xn, const float* __restrict__ coef,
+                                                          const int* __restrict__ step, long long n) {
+    const float* c = coef + (size_t)step[0] * 7;
+    const float a0 = c[1], a1 = c[2], m1 = c[3], m2 = c[4], den = c[5], sig = c[6];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float xv = x[i];
+        float p = __fsub_rn(__fmul_rn(a0, xv), __fmul_rn(a1, e[i]));
+        p = fminf(fmaxf(p, -1.0f), 1.0f);
+        x0[i] = p;
+        const float mean = __fdiv_rn(__fadd_rn(__fmul_rn(m1, p), __fmul_rn(m2, xv)), den);
+        xn[i] = __fadd_rn(mean, __fmul_rn(sig, noise[i]));
+    }
+}
+hipError_t ddpm_update_launch(const float* x, const float* e, const float* noise, float* x0, float* xn, const float* coef,
+                              const int* step, long long n, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(ddpm_update_kernel, dim3(blocks), dim3(256), 0, s, x, e, noise, x0, xn, coef, step, n);
     return hipGetLastError();
 }
 

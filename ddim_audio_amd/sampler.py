@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .schedule import ddim_coefficients
+from .schedule import ddim_coefficients, ddpm_coefficients
 
 
 def _selected(select_index, index, n):
@@ -104,4 +104,45 @@ def generalized_steps(x, seq, model, alpha, select_index, **kwargs):
             if _selected(select_index, index, n_iter):
                 x0_preds.append(stepper.x0.to("cpu"))
                 xs.append(xt.to("cpu"))
+    return xs, x0_preds
+
+
+def ddpm_steps(x, seq, model, b, select_index, **kwargs):
+    """Ancestral sampler of the reference (``functions/denoising.py:55-92``): same signature and return value
+    (every iteration appends the clamped x0 prediction and the new sample as CPU tensors; ``select_index`` must be
+    None like upstream).  ``b`` is the fp32 beta table.  The per-step update is one libddimx pass
+    (``ddimx_ddpm_update``); the noise is drawn with ``torch.randn_like`` like the reference (``noise_fn`` kwarg:
+    test hook returning the noise tensor for iteration k)."""
+    if select_index is not None:
+        raise NotImplementedError("Specifying select_index is not implemented in ddpm_steps.")
+    lib = _lib.load()
+    noise_fn = kwargs.get("noise_fn")
+    seq = list(seq)
+    device = None
+    if isinstance(model, torch.nn.Module):
+        p0 = next(model.parameters(), None)
+        if p0 is not None and p0.is_cuda:
+            device = p0.device
+    if device is None:
+        device = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    with torch.no_grad(), torch.cuda.device(device):
+        xs, x0_preds = [x], []
+        cur = x.to(device, torch.float32).contiguous().clone()
+        nxt, x0buf = torch.empty_like(cur), torch.empty_like(cur)
+        coef = torch.from_numpy(ddpm_coefficients(seq, b)).to(device).contiguous()
+        counter = torch.zeros(1, dtype=torch.int32, device=device)
+        t = torch.zeros(cur.size(0), dtype=torch.int64, device=device)
+        for k in range(len(seq)):
+            st = _lib.stream()
+            _lib.check(lib.ddimx_step_begin_ex(_lib.ptr(coef), 7, _lib.ptr(counter), _lib.ptr(t), t.numel(), st))
+            e = model(cur, t)
+            if e.dtype != torch.float32 or not e.is_contiguous():
+                e = e.float().contiguous()
+            noise = (noise_fn(k, cur) if noise_fn is not None else torch.randn_like(cur)).to(device, torch.float32).contiguous()
+            _lib.check(lib.ddimx_ddpm_update(_lib.ptr(cur), _lib.ptr(e), _lib.ptr(noise), _lib.ptr(x0buf), _lib.ptr(nxt),
+                                             _lib.ptr(coef), _lib.ptr(counter), cur.numel(), st))
+            _lib.check(lib.ddimx_step_end(_lib.ptr(counter), st))
+            x0_preds.append(x0buf.to("cpu"))
+            xs.append(nxt.to("cpu"))
+            cur, nxt = nxt, cur
     return xs, x0_preds

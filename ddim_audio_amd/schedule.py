@@ -74,3 +74,22 @@ def ddim_coefficients(seq, alpha, eta=0.0):
         c2 = ((1 - at_next) - c1 ** 2) ** 0.5
         rows.append((float(int(i)), (1 - at) ** 0.5, at ** 0.5, at_next ** 0.5, c2, c1))
     return np.asarray(rows, dtype=np.float64).reshape(-1, 6)
+
+
+def ddpm_coefficients(seq, betas):
+    """Per-iteration scalars of ``ddpm_steps`` (reference ``functions/denoising.py:4-7,64-88``), formed with the
+    reference's fp32 *tensor* arithmetic (it works on [n,1,1,1] fp32 tensors, not Python doubles).  Returns a float32
+    array [n_iter, 7] in execution order: (t, (1/at).sqrt(), (1/at-1).sqrt(), atm1.sqrt()*beta_t,
+    (1-beta_t).sqrt()*(1-atm1), 1-at, mask*exp(0.5*log(beta_t)))."""
+    b = torch.as_tensor(betas).to("cpu", torch.float32)
+    acp = (1 - torch.cat([torch.zeros(1), b], dim=0)).cumprod(dim=0)  # compute_alpha's table, index t+1
+    seq = list(seq)
+    seq_next = [-1] + seq[:-1]
+    rows = []
+    for i, j in zip(reversed(seq), reversed(seq_next)):
+        at, atm1 = acp[int(i) + 1], acp[int(j) + 1]
+        beta_t = 1 - at / atm1
+        mask = 1.0 - float(int(i) == 0)
+        rows.append(torch.stack([torch.tensor(float(int(i))), (1.0 / at).sqrt(), (1.0 / at - 1).sqrt(), atm1.sqrt() * beta_t,
+                                 (1 - beta_t).sqrt() * (1 - atm1), 1.0 - at, mask * torch.exp(0.5 * beta_t.log())]))
+    return torch.stack(rows).to(torch.float32).numpy()

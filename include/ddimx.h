@@ -139,8 +139,14 @@ int ddimx_temb_fwd(const float* te, const int64_t* t, const float* w0, const flo
  * step_begin fills t[B] with the current timestep; ddim_update performs lines :27 and :41-43 in one pass,
  * writing the x0 prediction to x0 and x_{t-1} in place; step_end advances the counter. */
 int ddimx_step_begin(const float* coef, const int* step, int64_t* t, int B, void* stream);
+/* as ddimx_step_begin for coefficient tables with another row stride (ddpm_steps: 7) */
+int ddimx_step_begin_ex(const float* coef, int row_stride, const int* step, int64_t* t, int B, void* stream);
 int ddimx_ddim_update(float* xt, const float* et, const float* noise, float* x0, const float* coef, const int* step,
                       long long n, void* stream);
+/* ddpm_steps update (functions/denoising.py:72-90): coef [n_iter][7] fp32 rows (t, (1/at).sqrt(), (1/at-1).sqrt(),
+ * atm1.sqrt()*beta_t, (1-beta_t).sqrt()*(1-atm1), 1-at, mask*exp(0.5*log(beta_t))); x0 = clamp(x0 pred), xn = sample */
+int ddimx_ddpm_update(const float* x, const float* et, const float* noise, float* x0, float* xn, const float* coef,
+                      const int* step, long long n, void* stream);
 int ddimx_step_end(int* step, void* stream);
 
 /* ---- training-step pieces (functions/losses.py:4-18, models/ema.py:16-23) ---------------------------- */

@@ -142,6 +142,8 @@ class _GpuSemantics:
         def to_(t, *a, **k):
             if a == ("cpu",) and not k:
                 return t.clone()
+            if a == ("cuda",) and not k:  # ddpm_steps re-uploads xs[-1] every iteration (:72)
+                return t
             return orig_to(t, *a, **k)
 
         torch.Tensor.type, torch.Tensor.to = type_, to_
@@ -163,6 +165,24 @@ def g7_sampler(out):
             out[f"samp_{name}_{sel_name}_xs"] = np.stack([np32(v) for v in xs])
             out[f"samp_{name}_{sel_name}_x0"] = np.stack([np32(v) for v in x0])
         out[f"samp_{name}_seq"] = np.asarray(seq, dtype=np.int64)
+    # ddpm_steps (ancestral sampler) with the analytic model and a deterministic noise sequence
+    betas = torch.from_numpy(np.load(os.path.join(OUT, "schedule.npz"))["betas"])
+    for name, seq in cases.items():
+        calls = {"k": 0}
+
+        def det_noise(ref):
+            calls["k"] += 1
+            return synth.gaussian(f"ddpm.noise.{name}.{calls['k'] - 1}", tuple(ref.shape))
+
+        orig_randn = torch.randn_like
+        torch.randn_like = det_noise
+        try:
+            with _GpuSemantics():
+                xs, x0 = ref_denoise.ddpm_steps(x.clone(), seq, fake, betas, None)
+        finally:
+            torch.randn_like = orig_randn
+        out[f"ddpm_{name}_xs"] = np.stack([np32(v) for v in xs])
+        out[f"ddpm_{name}_x0"] = np.stack([np32(v) for v in x0])
     # tiny real model, 10 steps: record every model input and the final sample
     cfg = configs.tiny_config(CPU)
     model = filled(ref_model.Model(cfg), seed=3)

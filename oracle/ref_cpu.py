@@ -174,6 +174,34 @@ def generalized_steps(x, seq, model_fn, alpha, select_index=None, eta=0.0, noise
     return xs, x0_preds
 
 
+def compute_alpha(beta, t):
+    """functions/denoising.py:4-7."""
+    beta = torch.cat([torch.zeros(1), beta], dim=0)
+    return (1 - beta).cumprod(dim=0).index_select(0, t + 1).view(-1, 1, 1, 1)
+
+
+def ddpm_steps(x, seq, model_fn, betas, noise_fn):
+    """functions/denoising.py:55-92 (select_index=None); ``noise_fn(k, x)`` supplies the Gaussian noise."""
+    n = x.size(0)
+    seq = list(seq)
+    seq_next = [-1] + seq[:-1]
+    xs, x0_preds = [x], []
+    for k, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
+        t = torch.ones(n) * i
+        next_t = torch.ones(n) * j
+        at = compute_alpha(betas, t.long())
+        atm1 = compute_alpha(betas, next_t.long())
+        beta_t = 1 - at / atm1
+        xc = xs[-1]
+        e = model_fn(xc, t.long())
+        x0 = torch.clamp((1.0 / at).sqrt() * xc - (1.0 / at - 1).sqrt() * e, -1, 1)
+        x0_preds.append(x0)
+        mean = ((atm1.sqrt() * beta_t) * x0 + ((1 - beta_t).sqrt() * (1 - atm1)) * xc) / (1.0 - at)
+        mask = (1 - (t == 0).float()).view(-1, 1, 1, 1)
+        xs.append(mean + mask * torch.exp(0.5 * beta_t.log()) * noise_fn(k, xc))
+    return xs, x0_preds
+
+
 def noise_estimation_loss(model_fn, x0, t, e, a, keepdim=False):
     """functions/losses.py:4-18."""
     at = a.index_select(0, t).view(-1, 1, 1, 1)

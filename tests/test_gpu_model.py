@@ -144,3 +144,22 @@ def test_loss_and_ema_golden(golden):
         assert torch.allclose(ema.shadow[k].cpu(), want[k], rtol=1e-6, atol=1e-8), k
     ema.ema(m)
     assert all(torch.equal(p.data, ema.shadow[k]) for k, p in m.named_parameters())
+
+
+def test_ddpm_steps_golden(golden):
+    """ddpm_steps through the fused HIP update against the reference trajectory (same injected noise)."""
+    gsamp, gsch = golden("sampler"), golden("schedule")
+    betas = torch.from_numpy(gsch["betas"])
+    fake = lambda x, t: 0.1 * x + 0.01 * t.float().view(-1, 1, 1, 1)  # noqa: E731
+    x = synth.gaussian("sampler.fake.x", (2, 2, 8, 16))
+    for name in ("u10", "quad8"):
+        seq = gsamp[f"samp_{name}_seq"].tolist()
+        nf = lambda k, ref, name=name: synth.gaussian(f"ddpm.noise.{name}.{k}", tuple(ref.shape))  # noqa: E731
+        xs, x0 = D.ddpm_steps(x.cuda(), seq, fake, betas, None, noise_fn=nf)
+        exs, ex0 = gsamp[f"ddpm_{name}_xs"], gsamp[f"ddpm_{name}_x0"]
+        assert len(xs) == len(exs) and len(x0) == len(ex0)
+        got = torch.stack([v.cpu() for v in xs[1:]]).numpy()
+        assert np.allclose(got, exs[1:], rtol=2e-5, atol=2e-5 * np.abs(exs).max())
+        assert np.allclose(torch.stack(x0).numpy(), ex0, rtol=2e-5, atol=2e-5)
+    with pytest.raises(NotImplementedError):
+        D.ddpm_steps(x.cuda(), [0, 500], fake, betas, [0])

@@ -110,3 +110,50 @@ def test_sharded_sampling_world2_gloo(n):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert sum(k for _, _, k in res) == n
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path, golden):
+    """[model_sd, optimizer_sd, epoch, step, ema_shadow] as the reference writes it; strict reload + EMA swap."""
+    from ddim_audio_amd import synth
+    from ddim_audio_amd.checkpoint import load_for_sampling, save_checkpoint
+    from ddim_audio_amd.ema import EMAHelper
+    from ddim_audio_amd.model import Model
+    cfg = configs.tiny_config("torch.FloatTensor")
+    m = synth.fill_module(Model(cfg), seed=1)
+    ema = EMAHelper(mu=0.9999)
+    ema.register(m)
+    for k in ema.shadow:
+        ema.shadow[k] = ema.shadow[k] * 0.5  # make the shadow differ from the parameters
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    states = save_checkpoint(str(tmp_path), m, opt, epoch=3, step=5000, ema_helper=ema)
+    assert len(states) == 5 and states[2] == 3 and states[3] == 5000
+    assert os.path.exists(tmp_path / "ckpt_5000.pth") and os.path.exists(tmp_path / "ckpt.pth")
+    raw = torch.load(tmp_path / "ckpt.pth", weights_only=False)
+    assert list(raw[0].keys()) == list(m.state_dict().keys()) and set(raw[-1].keys()) == {k for k, _ in m.named_parameters()}
+    m2, e2 = load_for_sampling(str(tmp_path), Model(cfg), use_ema=True)
+    assert not m2.training and m2._dirty  # weights swapped in: the packed copy must be rebuilt
+    for (k, p), (_, q) in zip(m2.named_parameters(), m.named_parameters()):
+        assert torch.equal(p, q * 0.5), k
+    m3, e3 = load_for_sampling(str(tmp_path), Model(cfg), use_ema=False, ckpt_id=5000)
+    assert e3 is None and all(torch.equal(p, q) for p, q in zip(m3.parameters(), m.parameters()))
+
+
+def test_ddpm_coefficients_reproduce_golden(golden):
+    """Host table of the ancestral sampler: numpy fp32 replay of the analytic-model trajectory (same op order)."""
+    from ddim_audio_amd import synth
+    g, gs = golden("sampler"), golden("schedule")
+    betas = torch.from_numpy(gs["betas"])
+    x0 = synth.gaussian("sampler.fake.x", (2, 2, 8, 16)).numpy()
+    for name in ("u10", "quad8"):
+        seq = g[f"samp_{name}_seq"].tolist()
+        coef = schedule.ddpm_coefficients(seq, betas)
+        assert coef.shape == (len(seq), 7) and coef.dtype == np.float32
+        x = x0.copy()
+        for k, (t, a0, a1, m1, m2, den, sig) in enumerate(coef):
+            e = (np.float32(0.1) * x + np.float32(0.01) * np.float32(t)).astype(np.float32)
+            p0 = np.clip((a0 * x).astype(np.float32) - (a1 * e).astype(np.float32), -1, 1).astype(np.float32)
+            mean = (((m1 * p0).astype(np.float32) + (m2 * x).astype(np.float32)).astype(np.float32) / den).astype(np.float32)
+            nz = synth.gaussian(f"ddpm.noise.{name}.{k}", x.shape).numpy()
+            x = (mean + (sig * nz).astype(np.float32)).astype(np.float32)
+            assert np.array_equal(p0, g[f"ddpm_{name}_x0"][k]), (name, k)
+            assert np.array_equal(x, g[f"ddpm_{name}_xs"][k + 1]), (name, k)

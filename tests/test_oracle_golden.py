@@ -174,3 +174,17 @@ def test_sampler_tiny_model_and_training(golden):
     sh = ref_cpu.ema_update(shadow, new, 0.9999)
     k = "down_modules.0.weight"
     assert np.allclose(sh[k].reshape(-1)[:64].numpy(), g["ema_shadow::" + k], rtol=1e-6, atol=1e-7)
+
+
+def test_ddpm_steps_fake_model(golden):
+    """Ancestral sampler restatement vs the reference's ddpm_steps run with the same deterministic noise."""
+    g, gs = golden("sampler"), golden("schedule")
+    betas = torch.from_numpy(gs["betas"])
+    fake = lambda x, t: 0.1 * x + 0.01 * t.float().view(-1, 1, 1, 1)  # noqa: E731
+    x = synth.gaussian("sampler.fake.x", (2, 2, 8, 16))
+    for name in ("u10", "quad8"):
+        seq = g[f"samp_{name}_seq"].tolist()
+        nf = lambda k, ref, name=name: synth.gaussian(f"ddpm.noise.{name}.{k}", tuple(ref.shape))  # noqa: E731
+        xs, x0 = ref_cpu.ddpm_steps(x.clone(), seq, fake, betas, nf)
+        assert np.array_equal(torch.stack(xs).numpy(), g[f"ddpm_{name}_xs"])
+        assert np.array_equal(torch.stack(x0).numpy(), g[f"ddpm_{name}_x0"])
