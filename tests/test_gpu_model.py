@@ -163,3 +163,54 @@ def test_ddpm_steps_golden(golden):
         assert np.allclose(torch.stack(x0).numpy(), ex0, rtol=2e-5, atol=2e-5)
     with pytest.raises(NotImplementedError):
         D.ddpm_steps(x.cuda(), [0, 500], fake, betas, [0])
+
+
+@pytest.mark.parametrize("dt", [G.F32, G.BF16])
+def test_model_edge_shapes_vs_oracle(audio_models, dt):
+    """T=96 (S=3: non-power-of-two sequence DFT / positional table, ragged tiles on every level) and an odd batch."""
+    cfg = configs.audio_config("torch.FloatTensor")
+    m = audio_models[dt]
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for tag, shape, t in (("t96", (1, 2, 96, 256), [640]), ("b5", (5, 2, 32, 256), [0, 1, 500, 998, 999])):
+        x = synth.gaussian("edge." + tag, shape)
+        tt = torch.tensor(t)
+        with torch.no_grad():
+            want = ref_cpu.model_forward(sd, cfg, x, tt)
+            got = m(x.cuda(), tt.cuda()).cpu()
+        G.check_close(got, want, dt, f"edge shape {tag}")
+
+
+def test_weight_cache_invalidation(audio_models):
+    """Packed weights must follow in-place parameter updates (optimizer steps), load_state_dict and EMA swaps."""
+    m = make_model(configs.tiny_config("torch.cuda.FloatTensor"), seed=5)
+    x = synth.gaussian("inval.x", (2, 2, 16, 32)).cuda()
+    t = torch.tensor([3, 700]).cuda()
+    with torch.no_grad():
+        y0 = m(x, t).clone()
+        w = dict(m.named_parameters())["down_modules.0.weight"]
+        w.mul_(1.5)  # in-place update bumps the tensor version -> repack
+        y1 = m(x, t).clone()
+        assert not torch.equal(y0, y1)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["down_modules.0.weight"] = sd["down_modules.0.weight"] / 1.5
+        m.load_state_dict(sd, strict=True)
+        y2 = m(x, t).clone()
+    assert torch.allclose(y2, y0, rtol=1e-5, atol=1e-5)
+    ema = D.EMAHelper(mu=0.5)
+    ema.register(m)
+    for k in ema.shadow:
+        ema.shadow[k] = ema.shadow[k] * 0.9
+    ema.ema(m)  # writes through .data (no version bump): EMAHelper must invalidate explicitly
+    with torch.no_grad():
+        y3 = m(x, t)
+    assert not torch.allclose(y3, y0, rtol=1e-3, atol=1e-3)
+
+
+def test_cpu_tensor_and_bad_shapes_raise(audio_models):
+    m = audio_models[G.F32]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 2, 32, 256), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 48, 256).cuda(), torch.zeros(1, dtype=torch.long).cuda())  # T not a multiple of 32
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 256).cuda(), torch.zeros(1, dtype=torch.long).cuda())  # wrong channel count

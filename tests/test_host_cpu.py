@@ -157,3 +157,17 @@ def test_ddpm_coefficients_reproduce_golden(golden):
             x = (mean + (sig * nz).astype(np.float32)).astype(np.float32)
             assert np.array_equal(p0, g[f"ddpm_{name}_x0"][k]), (name, k)
             assert np.array_equal(x, g[f"ddpm_{name}_xs"][k + 1]), (name, k)
+
+
+def test_product_package_never_touches_the_oracle_or_reference():
+    """The oracle is test infrastructure: nothing under ddim_audio_amd/ (or bench.py outside cpu_baseline) may import it."""
+    pkg = os.path.join(REPO, "ddim_audio_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                code = "\n".join(ln for ln in src.split("\n") if "import" in ln or "open(" in ln or "exec" in ln)
+                assert "oracle" not in code, os.path.join(root, f)  # docstrings may mention it; code may not use it
+                assert "/root/reference" not in src, os.path.join(root, f)
+    bench = open(os.path.join(REPO, "bench.py")).read()
+    assert bench.count("from oracle import") == 1 and "def cpu_baseline" in bench
