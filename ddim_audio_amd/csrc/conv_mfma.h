@@ -214,8 +214,17 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     const int wm = wave % C::WM, wn = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;
 
-    const int wg = blockIdx.x % a.wgs_per_sample;
-    const int bs = blockIdx.x / a.wgs_per_sample;
+    // XCD-aware order (speed only, never correctness): hardware deals consecutive blockIdx round-robin over the 8
+    // XCDs, each with its own L2.  Give every XCD a contiguous range of logical workgroups so that workgroups of
+    // neighbouring tile ranges -- which re-read each other's halo rows -- share an L2 (bijective for any grid size).
+    int lwg;
+    {
+        const int nwg = gridDim.x, x8 = blockIdx.x & 7, i8 = blockIdx.x >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        lwg = (x8 < r ? x8 * (q + 1) : r * (q + 1) + (x8 - r) * q) + i8;
+    }
+    const int wg = lwg % a.wgs_per_sample;
+    const int bs = lwg / a.wgs_per_sample;
     const int cout0 = blockIdx.y * NB;
     const int cls = blockIdx.z;  // UP4 row-parity class; 0 otherwise
     const int ntile_s = a.tiles_x * a.tiles_y;
