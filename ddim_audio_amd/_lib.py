@@ -63,6 +63,9 @@ _SIGS = {
     "ddimx_sqerr_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     "ddimx_ema_block_elems": (c_int, []),
     "ddimx_ema_update_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "ddimx_grad_norm_multi": (c_int, [c_void_p] * 4 + [c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "ddimx_scale_multi": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),
+    "ddimx_adam_multi": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -3,6 +3,7 @@
 #include "../../include/ddimx.h"
 
 #include <stdarg.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -723,6 +724,29 @@ int ddimx_ema_block_elems(void) { return ema_block_elems(); }
 int ddimx_ema_update_multi(const long long* shadow_ptrs, const long long* param_ptrs, const long long* sizes,
                            const int* blk_tensor, const long long* blk_off, int nblocks, float mu, void* stream) {
     HIPCHK(ema_multi_launch(shadow_ptrs, param_ptrs, sizes, blk_tensor, blk_off, nblocks, mu, (hipStream_t)stream));
+    return 0;
+}
+
+int ddimx_grad_norm_multi(const long long* grad_ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                          int nblocks, float max_norm, float* partial, float* out, void* stream) {
+    HIPCHK(grad_norm_multi_launch(grad_ptrs, sizes, blk_tensor, blk_off, nblocks, max_norm, partial, out, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_scale_multi(const long long* ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks,
+                      const float* coef, void* stream) {
+    HIPCHK(scale_multi_launch(ptrs, sizes, blk_tensor, blk_off, nblocks, coef, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_adam_multi(const long long* param_ptrs, const long long* grad_ptrs, const long long* m_ptrs, const long long* v_ptrs,
+                     const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks, const float* clip,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, int decoupled, void* stream) {
+    if (step < 1) return fail("ddimx_adam_multi: step must be >= 1");
+    AdamArgs a;
+    a.p = param_ptrs; a.g = grad_ptrs; a.m = m_ptrs; a.v = v_ptrs; a.sizes = sizes; a.blk_tensor = blk_tensor; a.blk_off = blk_off;
+    a.clip = clip; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.decoupled = decoupled;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    HIPCHK(adam_multi_launch(a, nblocks, (hipStream_t)stream));
     return 0;
 }
 

@@ -75,6 +75,17 @@ int sqerr_nparts();
 hipError_t ema_multi_launch(const long long* shadow_ptrs, const long long* param_ptrs, const long long* sizes,
                             const int* blk_tensor, const long long* blk_off, int nblocks, float mu, hipStream_t s);
 int ema_block_elems();
+// training-step tail (multi-tensor, pointer tables as for ema_multi)
+hipError_t grad_norm_multi_launch(const long long* ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                                  int nblocks, float max_norm, float* partial, float* out, hipStream_t s);
+struct AdamArgs {
+    const long long* p; const long long* g; const long long* m; const long long* v; const long long* sizes;
+    const int* blk_tensor; const long long* blk_off; const float* clip;
+    float lr, b1, b2, eps, wd, bc1, bc2s; int decoupled;
+};
+hipError_t adam_multi_launch(const AdamArgs& a, int nblocks, hipStream_t s);
+hipError_t scale_multi_launch(const long long* ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                              int nblocks, const float* coef, hipStream_t s);
 
 // ---- weight packing ------------------------------------------------------------------------------------
 hipError_t pack_copy_launch(const float* src, float* dst, long long n, hipStream_t s);

@@ -774,6 +774,100 @@ hipError_t ema_multi_launch(const long long* shadow_ptrs, const long long* param
     return hipGetLastError();
 }
 
+
+// =====================================================================================================
+// training-step tail (runners/diffusion.py:155-173): multi-tensor kernels over pointer tables, one launch each
+// =====================================================================================================
+// sum of squares of all gradient tensors: per-block partials (fixed order) then one block finishes:
+// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_)
+__global__ void __launch_bounds__(256) sqnorm_multi_kernel(const long long* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                           const int* __restrict__ blk_tensor, const long long* __restrict__ blk_off,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int ti = blk_tensor[blockIdx.x];
+    const float* g = (const float*)ptrs[ti];
+    const long long n = sizes[ti], off = blk_off[blockIdx.x];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < kEmaBlock; i += 256) {
+        const long long k = off + i;
+        if (k < n) s = fmaf(g[k], g[k], s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) sqnorm_final_kernel(const float* __restrict__ partial, int n, float max_norm,
+                                                           float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        const float coef = max_norm / (norm + 1e-6f);
+        out[0] = norm;
+        out[1] = coef < 1.0f ? coef : 1.0f;
+    }
+}
+hipError_t grad_norm_multi_launch(const long long* ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                                  int nblocks, float max_norm, float* partial, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(nblocks), dim3(256), 0, s, ptrs, sizes, blk_tensor, blk_off, partial);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, max_norm, out);
+    return hipGetLastError();
+}
+
+// g *= coef[1] (the clip coefficient stays on the device: no host sync), then Adam / AdamW (torch semantics,
+// amsgrad off): decoupled: p *= 1 - lr*wd ; else g += wd*p.  m = m + (1-b1)(g - m); v = b2*v + (1-b2) g*g;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t) from the host.
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamArgs a) {
+    const int ti = a.blk_tensor[blockIdx.x];
+    float* p = (float*)a.p[ti];
+    float* g = (float*)a.g[ti];
+    float* m = (float*)a.m[ti];
+    float* v = (float*)a.v[ti];
+    const long long n = a.sizes[ti], off = a.blk_off[blockIdx.x];
+    const float cc = a.clip ? a.clip[1] : 1.0f;
+    const float step_size = a.lr / a.bc1;
+    for (int i = threadIdx.x; i < kEmaBlock; i += 256) {
+        const long long k = off + i;
+        if (k >= n) continue;
+        float gk = __fmul_rn(g[k], cc);
+        float pk = p[k];
+        if (a.decoupled) pk = __fmul_rn(pk, 1.0f - a.lr * a.wd);
+        else gk = fmaf(a.wd, pk, gk);
+        const float mk = fmaf(1.0f - a.b1, __fsub_rn(gk, m[k]), m[k]);
+        const float vk = fmaf(__fmul_rn(gk, gk), 1.0f - a.b2, __fmul_rn(v[k], a.b2));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vk), a.bc2s), a.eps);
+        pk = fmaf(-step_size, __fdiv_rn(mk, denom), pk);
+        g[k] = gk; m[k] = mk; v[k] = vk; p[k] = pk;
+    }
+}
+__global__ void __launch_bounds__(256) scale_multi_kernel(const long long* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                          const int* __restrict__ blk_tensor, const long long* __restrict__ blk_off,
+                                                          const float* __restrict__ coef) {
+    const int ti = blk_tensor[blockIdx.x];
+    float* g = (float*)ptrs[ti];
+    const long long n = sizes[ti], off = blk_off[blockIdx.x];
+    const float c = coef[0];
+    if (c == 1.0f) return;  // torch multiplies by the clamped coefficient; x * 1.0f is the identity
+    for (int i = threadIdx.x; i < kEmaBlock; i += 256) {
+        const long long k = off + i;
+        if (k < n) g[k] = __fmul_rn(g[k], c);
+    }
+}
+hipError_t scale_multi_launch(const long long* ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                              int nblocks, const float* coef, hipStream_t s) {
+    hipLaunchKernelGGL(scale_multi_kernel, dim3(nblocks), dim3(256), 0, s, ptrs, sizes, blk_tensor, blk_off, coef);
+    return hipGetLastError();
+}
+hipError_t adam_multi_launch(const AdamArgs& a, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // =====================================================================================================
 // weight packing (fp32 parameters -> internal layouts)
 // =====================================================================================================

@@ -1,11 +1,17 @@
-"""Optimizer / LR-schedule factories of the training-step tail (reference ``functions/__init__.py:5-60``).
+"""Optimizer tail of the training step (reference ``functions/__init__.py:5-60``, ``runners/diffusion.py:155-173``).
 
-Round-1 status: thin pass-through to ``torch.optim`` so the reference runner's call sites resolve;
-the fused multi-tensor HIP optimizer (and AdaBelief, whose source is an un-vendored submodule of the
-reference) is SURVEY section 8f row 1 and not built yet.
+``get_optimizer`` returns fused multi-tensor optimizers for ``Adam`` / ``AdamW`` (one libddimx launch per group
+instead of ~10 tiny launches per tensor); ``clip_grad_norm_`` is the fused counterpart of
+``torch.nn.utils.clip_grad_norm_`` (global L2 norm + in-place scaling, the coefficient never leaves the device).
+``AdaBelief`` lives in an un-vendored submodule of the reference (``External/step-clip-optimizer``): its source is
+absent, so it is not reproduced here (parity would be unpinned) -- requesting it raises.  RMSProp / SGD pass through
+to ``torch.optim``.  CPU tensors are rejected: like the rest of the package there is no CPU fallback.
 """
+import torch
 import torch.optim as optim
 from torch.optim.lr_scheduler import LambdaLR
+
+from . import _lib
 
 
 def lr_factor(step, warmup):
@@ -13,13 +19,111 @@ def lr_factor(step, warmup):
     return min(((1 + step) / warmup) ** -0.5, (1 + step) / warmup)
 
 
+class _Tables:
+    """Device pointer / size / block tables over a list of equally-shaped tensor lists (cached per pointer set)."""
+
+    def __init__(self, lists, device):
+        blk = _lib.load().ddimx_ema_block_elems()
+        self.key = tuple(t.data_ptr() for ts in lists for t in ts)
+        sizes, bt, bo = [], [], []
+        for i, t in enumerate(lists[0]):
+            sizes.append(t.numel())
+            for off in range(0, t.numel(), blk):
+                bt.append(i); bo.append(off)
+        mk = lambda v, dt: torch.tensor(v, dtype=dt, device=device)  # noqa: E731
+        self.ptrs = [mk([t.data_ptr() for t in ts], torch.int64) for ts in lists]
+        self.sizes, self.bt, self.bo, self.nblk = mk(sizes, torch.int64), mk(bt, torch.int32), mk(bo, torch.int64), len(bt)
+
+
+def _check(ts, what):
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"{what}: tensors must be contiguous fp32 on the GPU (no CPU fallback)")
+
+
+_clip_cache = {}
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0):
+    """Fused ``torch.nn.utils.clip_grad_norm_`` (L2 only): returns the total norm as a 0-dim device tensor."""
+    if float(norm_type) != 2.0:
+        raise NotImplementedError("only the L2 norm is implemented")
+    grads = [p.grad for p in ([parameters] if isinstance(parameters, torch.Tensor) else parameters) if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.0)
+    _check(grads, "clip_grad_norm_")
+    dev = grads[0].device
+    key = tuple(g.data_ptr() for g in grads)
+    tb = _clip_cache.get(key)
+    if tb is None:
+        _clip_cache.clear()
+        tb = _clip_cache[key] = _Tables([grads], dev)
+        tb.partial = torch.empty(tb.nblk, dtype=torch.float32, device=dev)
+        tb.out = torch.empty(2, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ddimx_grad_norm_multi(_lib.ptr(tb.ptrs[0]), _lib.ptr(tb.sizes), _lib.ptr(tb.bt), _lib.ptr(tb.bo), tb.nblk,
+                                             float(max_norm), _lib.ptr(tb.partial), _lib.ptr(tb.out), _lib.stream()))
+        _lib.check(lib.ddimx_scale_multi(_lib.ptr(tb.ptrs[0]), _lib.ptr(tb.sizes), _lib.ptr(tb.bt), _lib.ptr(tb.bo), tb.nblk,
+                                         _lib.ptr(tb.out[1:]), _lib.stream()))
+    return tb.out[0]
+
+
+class FusedAdam(optim.Optimizer):
+    """``torch.optim.Adam`` (``decoupled=False``) / ``AdamW`` (``decoupled=True``) semantics, amsgrad off, one
+    multi-tensor HIP launch per parameter group.  ``param_groups[i]['lr']`` is honoured, so ``LambdaLR`` works."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, decoupled=True):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not implemented in the fused optimizer")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, decoupled=decoupled))
+        self._tables = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+            steps = {self.state[p]["step"] for p in ps}
+            if len(steps) != 1:
+                raise RuntimeError("FusedAdam: parameters of one group must share the step count")
+            lists = [[p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
+                     [self.state[p]["exp_avg_sq"] for p in ps]]
+            for ts in lists:
+                _check(ts, "FusedAdam")
+            dev = ps[0].device
+            key = tuple(t.data_ptr() for ts in lists for t in ts)
+            tb = self._tables.get(gi)
+            if tb is None or tb.key != key:
+                tb = self._tables[gi] = _Tables(lists, dev)
+            b1, b2 = group["betas"]
+            with torch.cuda.device(dev):
+                _lib.check(lib.ddimx_adam_multi(_lib.ptr(tb.ptrs[0]), _lib.ptr(tb.ptrs[1]), _lib.ptr(tb.ptrs[2]), _lib.ptr(tb.ptrs[3]),
+                                                _lib.ptr(tb.sizes), _lib.ptr(tb.bt), _lib.ptr(tb.bo), tb.nblk, None, float(group["lr"]),
+                                                float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                int(steps.pop()), 1 if group["decoupled"] else 0, _lib.stream()))
+        return loss
+
+
 def get_optimizer(config, parameters):
-    kw = dict(lr=config.lr, weight_decay=config.weight_decay)
     if config.optimizer in ("Adam", "AdamW"):
-        cls = optim.Adam if config.optimizer == "Adam" else optim.AdamW
-        return cls(parameters, betas=tuple(config.beta), amsgrad=config.amsgrad, eps=config.eps, **kw)
+        return FusedAdam(parameters, lr=config.lr, weight_decay=config.weight_decay, betas=config.beta, amsgrad=config.amsgrad,
+                         eps=config.eps, decoupled=config.optimizer == "AdamW")
+    if config.optimizer == "AdaBelief":
+        raise NotImplementedError("AdaBelief comes from the reference's un-vendored step-clip-optimizer submodule (source "
+                                  "absent): use AdamW for this group")
     if config.optimizer == "RMSProp":
-        return optim.RMSprop(parameters, **kw)
+        return optim.RMSprop(parameters, lr=config.lr, weight_decay=config.weight_decay)
     if config.optimizer == "SGD":
         return optim.SGD(parameters, lr=config.lr, momentum=0.9)
     raise NotImplementedError("Optimizer {} not understood.".format(config.optimizer))

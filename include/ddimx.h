@@ -160,6 +160,21 @@ int ddimx_ema_block_elems(void);
 int ddimx_ema_update_multi(const long long* shadow_ptrs, const long long* param_ptrs, const long long* sizes,
                            const int* blk_tensor, const long long* blk_off, int nblocks, float mu, void* stream);
 
+/* ---- optimizer tail of train_step (runners/diffusion.py:155-173; functions/__init__.py:5-23) ------------------
+ * Multi-tensor launches over device pointer tables (block tables as for ddimx_ema_update_multi).
+ * grad_norm: out[0] = global L2 norm of all gradients, out[1] = min(1, max_norm/(norm+1e-6)) -- the coefficient of
+ * torch.nn.utils.clip_grad_norm_ -- kept on the device (no host sync); partial: [nblocks] scratch.
+ * adam: g *= clip[1] (if clip != null), then torch.optim.Adam (decoupled = 0) / AdamW (decoupled = 1), amsgrad off. */
+int ddimx_grad_norm_multi(const long long* grad_ptrs, const long long* sizes, const int* blk_tensor,
+                          const long long* blk_off, int nblocks, float max_norm, float* partial, float* out, void* stream);
+/* every tensor *= coef[0] (device scalar): the in-place scaling of clip_grad_norm_ */
+int ddimx_scale_multi(const long long* ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                      int nblocks, const float* coef, void* stream);
+int ddimx_adam_multi(const long long* param_ptrs, const long long* grad_ptrs, const long long* m_ptrs,
+                     const long long* v_ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                     int nblocks, const float* clip, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int step, int decoupled, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,32 @@ def test_cpu_tensor_and_bad_shapes_raise(audio_models):
         m(torch.zeros(1, 2, 48, 256).cuda(), torch.zeros(1, dtype=torch.long).cuda())  # T not a multiple of 32
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 32, 256).cuda(), torch.zeros(1, dtype=torch.long).cuda())  # wrong channel count
+
+
+def test_fused_adam_and_clip_match_torch():
+    """Fused multi-tensor clip_grad_norm_ + Adam/AdamW + LambdaLR against torch's own CPU implementations."""
+    from ddim_audio_amd import optim as O
+    shapes = [(64, 32, 3, 3), (64,), (512, 128), (4416,), (7,), (96, 96, 3, 3)]
+    for decoupled in (True, False):
+        ps_cpu = [torch.nn.Parameter(synth.gaussian(f"opt.p{i}", s) * 0.3) for i, s in enumerate(shapes)]
+        ps_gpu = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps_cpu]
+        ref = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ps_cpu, lr=5e-4, betas=(0.9, 0.998), eps=1e-6, weight_decay=1e-2)
+        cfg = configs.dict2namespace(dict(optimizer="AdamW" if decoupled else "Adam", lr=5e-4, weight_decay=1e-2, beta=[0.9, 0.998],
+                                          amsgrad=False, eps=1e-6, warmup=3))
+        ours = O.get_optimizer(cfg, ps_gpu)
+        sch_ref = torch.optim.lr_scheduler.LambdaLR(ref, lambda s: O.lr_factor(s, 3))
+        sch = O.get_scheduler(cfg, ours)
+        for it in range(5):
+            for i, (pc, pg) in enumerate(zip(ps_cpu, ps_gpu)):
+                g = synth.gaussian(f"opt.g{it}.{i}", tuple(pc.shape)) * (4.0 if it % 2 == 0 else 0.01)
+                pc.grad, pg.grad = g.clone(), g.clone().cuda()
+            n_ref = torch.nn.utils.clip_grad_norm_(ps_cpu, 1.0)
+            n_ours = O.clip_grad_norm_(ps_gpu, 1.0)
+            assert abs(float(n_ours) - float(n_ref)) <= 2e-6 * float(n_ref)
+            for pc, pg in zip(ps_cpu, ps_gpu):
+                assert torch.allclose(pg.grad.cpu(), pc.grad, rtol=2e-6, atol=1e-9)
+            ref.step(); ours.step(); sch_ref.step(); sch.step()
+            for pc, pg in zip(ps_cpu, ps_gpu):
+                assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=3e-6, atol=3e-7), (decoupled, it)
+    with pytest.raises(NotImplementedError):
+        O.get_optimizer(configs.dict2namespace(dict(optimizer="AdaBelief")), ps_gpu)
