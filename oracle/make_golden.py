@@ -226,9 +226,85 @@ def g7_sampler(out):
     out["ema_param::down_modules.0.weight"] = np32(dict(model.named_parameters())["down_modules.0.weight"]).reshape(-1)[:64]
 
 
+def _grad_digest(out, tag, model):
+    """Per-parameter gradient digest: L2 norm (float64) + a strided sample of <= 256 elements."""
+    names, norms = [], []
+    for name, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        names.append(name)
+        norms.append(float(g.double().square().sum()) ** 0.5)
+        stride = max(1, g.numel() // 256)
+        out[f"{tag}_g::{name}"] = np32(g[::stride][:256])
+    out[f"{tag}_names"] = np.asarray(names)
+    out[f"{tag}_gnorms"] = np.asarray(norms, dtype=np.float64)
+
+
+def g8_train(out):
+    """Training-mode forward/backward of the real reference (dropout probability 0 so that it is deterministic),
+    then two optimisation steps through the reference's own get_optimizer / get_scheduler / EMAHelper and
+    torch's clip_grad_norm_ -- the tail of Diffusion.train_step (runners/diffusion.py:130-173) with fixed (x0, e, t).
+    AdaBelief's source is absent, so the default group uses Adam with the default group's hyper-parameters."""
+    alphas = torch.from_numpy(np.load(os.path.join(OUT, "schedule.npz"))["alphas"])
+    for tag, cfgd, shape, tt, seed in (("tiny", configs.tiny_dict(CPU), (2, 2, 16, 32), [123, 876], 3),
+                                       ("audio", configs.audio_dict(CPU), (2, 2, 32, 256), [37, 911], 0)):
+        cfgd["model"]["transformers"]["kwargs"]["hidden_dropout_prob"] = 0.0
+        cfg = configs.dict2namespace(cfgd)
+        model = filled(ref_model.Model(cfg), seed=seed)
+        model.train()
+        x0 = synth.gaussian(f"train.{tag}.x0", shape)
+        e = synth.gaussian(f"train.{tag}.e", shape)
+        t = torch.tensor(tt)
+        out[f"{tag}_t"] = np.asarray(tt, dtype=np.int64)
+        loss = ref_losses.noise_estimation_loss(model, x0, t, e, alphas)
+        out[f"{tag}_loss"] = np.asarray(float(loss), dtype=np.float64)
+        loss.backward()
+        _grad_digest(out, tag, model)
+        if tag != "tiny":
+            continue
+        # ---- two full optimisation steps on the tiny model
+        opt_cfg = cfg.optimization.optimizer
+        opt_cfg.default.optimizer = "Adam"
+        groups = ref_runner.classify_group(opt_cfg, model)
+        optimizers = {k: ref_functions.get_optimizer(v.config, v.params) for k, v in groups.items()}
+        schedulers = {k: ref_functions.get_scheduler(groups[k].config, o) for k, o in optimizers.items()}
+        clip_groups = ref_runner.classify_group(cfg.optimization.grad_norm, model)
+        ema = ref_ema.EMAHelper(mu=0.9999)
+        ema.register(model)
+        for it in range(2):
+            if it:
+                model.transformer.embedding.te = None
+                x0 = synth.gaussian(f"train.{tag}.x0.{it}", shape)
+                e = synth.gaussian(f"train.{tag}.e.{it}", shape)
+                loss = ref_losses.noise_estimation_loss(model, x0, torch.tensor([5, 994]), e, alphas)
+                for o in optimizers.values():
+                    o.zero_grad()
+                loss.backward()
+            out[f"step{it}_loss"] = np.asarray(float(loss), dtype=np.float64)
+            for name, g in clip_groups.items():
+                out[f"step{it}_norm_{name}"] = np.asarray(float(torch.nn.utils.clip_grad_norm_(g.params, g.config.grad_clip)))
+            for o in optimizers.values():
+                o.step()
+            for s in schedulers.values():
+                s.step()
+            ema.update(model)
+            for name, p in model.named_parameters():
+                stride = max(1, p.numel() // 64)
+                out[f"step{it}_p::{name}"] = np32(p.reshape(-1)[::stride][:64])
+                out[f"step{it}_ema::{name}"] = np32(ema.shadow[name].reshape(-1)[::stride][:64])
+        out["step_lrs"] = np.asarray([o.param_groups[0]["lr"] for o in optimizers.values()], dtype=np.float64)
+        out["step_groups"] = np.asarray(list(optimizers.keys()))
+        out["step_group_sizes"] = np.asarray([len(g.params) for g in groups.values()])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["train"]:  # only the training fixtures (the others are unchanged)
+        train = {}
+        g8_train(train)
+        np.savez_compressed(os.path.join(OUT, "train.npz"), **train)
+        print("train.npz", os.path.getsize(os.path.join(OUT, "train.npz")))
+        return
     sched, blocks, model, sampler = {}, {}, {}, {}
     g1_schedule(sched)
     np.savez_compressed(os.path.join(OUT, "schedule.npz"), **sched)
@@ -240,6 +316,9 @@ def main():
     g7_sampler(sampler)
     sampler.pop("alphas")
     np.savez_compressed(os.path.join(OUT, "sampler.npz"), **sampler)
+    train = {}
+    g8_train(train)
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **train)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

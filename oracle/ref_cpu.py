@@ -219,3 +219,62 @@ def ema_update(shadow, params, mu):
 def lr_factor(step, warmup):
     """functions/__init__.py:53-60."""
     return min(((1 + step) / warmup) ** -0.5, (1 + step) / warmup)
+
+
+# ----------------------------------------------------------------------------- training step
+def classify_group(names, group_cfg):
+    """runners/diffusion.py:71-87 -- route parameter names by their top-level module name; groups without
+    parameters are dropped.  ``group_cfg``: Namespace {group: Namespace(top_level_name=[...], ...)}."""
+    top = {}
+    for gname, sub in vars(group_cfg).items():
+        for n in sub.top_level_name:
+            top[n] = gname
+    groups = {gname: [] for gname in vars(group_cfg)}
+    for n in names:
+        groups[top.get(n.split(".")[0], "default")].append(n)
+    return {k: v for k, v in groups.items() if v}
+
+
+def make_optimizer(ocfg, params):
+    """functions/__init__.py:5-23 (Adam / AdamW rows; AdaBelief's source is absent from the reference tree)."""
+    cls = {"Adam": torch.optim.Adam, "AdamW": torch.optim.AdamW}[ocfg.optimizer]
+    return cls(params, lr=ocfg.lr, weight_decay=ocfg.weight_decay, betas=tuple(ocfg.beta), amsgrad=ocfg.amsgrad, eps=ocfg.eps)
+
+
+class TrainState:
+    """Parameters (leaf tensors), optimizers, LambdaLR schedulers and the EMA shadow of one training run."""
+
+    def __init__(self, sd, cfg):
+        self.cfg = cfg
+        self.buffers = {"temb.te": sd["temb.te"]}
+        self.params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "temb.te"}
+        ocfg = cfg.optimization.optimizer
+        self.groups = classify_group(self.params.keys(), ocfg)
+        self.optimizers = {g: make_optimizer(getattr(ocfg, g), [self.params[n] for n in names])
+                           for g, names in self.groups.items()}
+        self.schedulers = {g: torch.optim.lr_scheduler.LambdaLR(o, lambda s, w=getattr(ocfg, g).warmup: lr_factor(s, w))
+                           for g, o in self.optimizers.items() if getattr(ocfg, g).warmup}
+        self.clip_groups = classify_group(self.params.keys(), cfg.optimization.grad_norm)
+        self.shadow = {k: v.detach().clone() for k, v in self.params.items()}
+
+
+def train_step(st, x0, e, t, alphas, mu=0.9999):
+    """runners/diffusion.py:130-173 with (e, t) supplied by the caller: loss, backward, per-group clip, optimizer and
+    scheduler steps, EMA.  Returns (loss, {clip group: total norm before clipping})."""
+    live = dict(st.params, **st.buffers)
+    loss = noise_estimation_loss(lambda a, b: model_forward(live, st.cfg, a, b), x0, t, e, alphas)
+    for o in st.optimizers.values():
+        o.zero_grad()
+    loss.backward()
+    norms = {}
+    for g, names in st.clip_groups.items():
+        clip = getattr(st.cfg.optimization.grad_norm, g).grad_clip
+        if clip is not None:
+            norms[g] = float(torch.nn.utils.clip_grad_norm_([st.params[n] for n in names], clip))
+    for o in st.optimizers.values():
+        o.step()
+    for s in st.schedulers.values():
+        s.step()
+    with torch.no_grad():
+        st.shadow = ema_update(st.shadow, {k: v.detach() for k, v in st.params.items()}, mu)
+    return float(loss), norms

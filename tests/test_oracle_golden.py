@@ -188,3 +188,58 @@ def test_ddpm_steps_fake_model(golden):
         xs, x0 = ref_cpu.ddpm_steps(x.clone(), seq, fake, betas, nf)
         assert np.array_equal(torch.stack(xs).numpy(), g[f"ddpm_{name}_xs"])
         assert np.array_equal(torch.stack(x0).numpy(), g[f"ddpm_{name}_x0"])
+
+
+def _train_cfg(name):
+    d = configs.tiny_dict(CPU) if name == "tiny" else configs.audio_dict(CPU)
+    d["model"]["transformers"]["kwargs"]["hidden_dropout_prob"] = 0.0
+    d["optimization"]["optimizer"]["default"]["optimizer"] = "Adam"  # AdaBelief source absent upstream
+    return configs.dict2namespace(d)
+
+
+@pytest.mark.parametrize("name,shape,seed", [("tiny", (2, 2, 16, 32), 3), ("audio", (2, 2, 32, 256), 0)])
+def test_training_gradients(golden, name, shape, seed):
+    """Training-mode loss + every parameter gradient of the reference (digest) vs autograd through the oracle."""
+    g, alphas = golden("train"), torch.from_numpy(golden("schedule")["alphas"])
+    cfg = _train_cfg(name)
+    sd = full_state(cfg, seed=seed)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "temb.te"}
+    live = dict(params, **{"temb.te": sd["temb.te"]})
+    x0, e = synth.gaussian(f"train.{name}.x0", shape), synth.gaussian(f"train.{name}.e", shape)
+    loss = ref_cpu.noise_estimation_loss(lambda a, b: ref_cpu.model_forward(live, cfg, a, b), x0, torch.from_numpy(g[f"{name}_t"]),
+                                         e, alphas)
+    assert abs(float(loss) - float(g[f"{name}_loss"])) < 1e-5 * float(g[f"{name}_loss"])
+    loss.backward()
+    total = float(np.sqrt((g[f"{name}_gnorms"] ** 2).sum()))
+    for pname, ref_norm in zip(g[f"{name}_names"], g[f"{name}_gnorms"]):
+        grad = params[str(pname)].grad.reshape(-1)
+        got = float(grad.double().square().sum()) ** 0.5
+        assert abs(got - ref_norm) <= 2e-4 * ref_norm + 1e-7 * total, pname
+        ref = g[f"{name}_g::{pname}"]
+        stride = max(1, grad.numel() // 256)
+        assert np.abs(grad[::stride][:256].numpy() - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-7 * total, pname
+
+
+def test_training_steps(golden):
+    """Two optimisation steps (clip, Adam/AdamW, LambdaLR, EMA) of the reference's train_step tail."""
+    g, alphas = golden("train"), torch.from_numpy(golden("schedule")["alphas"])
+    cfg = _train_cfg("tiny")
+    st = ref_cpu.TrainState(full_state(cfg, seed=3), cfg)
+    assert list(st.groups.keys()) == [str(s) for s in g["step_groups"]]
+    assert [len(v) for v in st.groups.values()] == list(g["step_group_sizes"])
+    shape = (2, 2, 16, 32)
+    for it in range(2):
+        sfx = f".{it}" if it else ""
+        x0, e = synth.gaussian(f"train.tiny.x0{sfx}", shape), synth.gaussian(f"train.tiny.e{sfx}", shape)
+        t = torch.tensor([5, 994]) if it else torch.from_numpy(g["tiny_t"])
+        loss, norms = ref_cpu.train_step(st, x0, e, t, alphas)
+        assert abs(loss - float(g[f"step{it}_loss"])) < 2e-5 * float(g[f"step{it}_loss"])
+        for k, v in norms.items():
+            assert abs(v - float(g[f"step{it}_norm_{k}"])) < 2e-4 * v
+        for n, p in st.params.items():
+            stride = max(1, p.numel() // 64)
+            ref = g[f"step{it}_p::{n}"]
+            assert np.abs(p.detach().reshape(-1)[::stride][:64].numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 2e-6, (it, n)
+            ref = g[f"step{it}_ema::{n}"]
+            assert np.abs(st.shadow[n].reshape(-1)[::stride][:64].numpy() - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-7, (it, n)
+    assert np.allclose([o.param_groups[0]["lr"] for o in st.optimizers.values()], g["step_lrs"], rtol=1e-12)
