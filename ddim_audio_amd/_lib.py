@@ -43,6 +43,11 @@ _SIGS = {
     "ddimx_op_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "ddimx_resblock_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 8 +
                            [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddimx_rb_tape_floats": (c_longlong, [c_int, c_int]),
+    "ddimx_resblock_fwd_train": (c_int, [c_int, c_int] + [c_void_p] * 3 + [c_int] + [c_void_p] * 12 + [c_int] * 3 + [c_void_p]),
+    "ddimx_pack_conv_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddimx_resblock_bwd_workspace_bytes": (c_longlong, [c_int] * 5),
+    "ddimx_resblock_bwd": (c_int, [c_int, c_int] + [c_void_p] * 20 + [c_int, c_void_p] + [c_int] * 3 + [c_void_p]),
     "ddimx_conv3x3_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddimx_conv3x3_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),

@@ -13,6 +13,8 @@
 
 #include "conv_mfma.h"
 #include "kernels.h"
+#include "train_kernels.h"
+#include "wgrad_mfma.h"
 
 namespace ddimx {
 hipError_t conv_geometry_bf16_c3(int, int, int, int, ConvGeom*);
@@ -376,25 +378,136 @@ struct RBPtrs {
     const void *w0, *w1;
 };
 
+// What the training forward of one Residual_Block keeps for its backward: the two pre-activation tensors and the
+// GroupNorm constants.  small: [6][B][C] folded (scale, shift) of GN0, GN1, GN2 then [3][B][8][2] (mean, rstd).
+struct RBTape {
+    void *u1, *u2;
+    float* small;
+    float* sc(int i, int B, int C) const { return small + (size_t)(2 * i) * B * C; }
+    float* sh(int i, int B, int C) const { return small + (size_t)(2 * i + 1) * B * C; }
+    float* mr(int i, int B, int C) const { return small + (size_t)6 * B * C + (size_t)i * B * kGroups * 2; }
+};
+static inline size_t rb_tape_small_floats(int B, int C) { return (size_t)6 * B * C + (size_t)3 * B * kGroups * 2; }
+
 // Residual_Block (models/diffusion.py:42-56).  The stats of x must already be in `stats`
 // ([B][x_nparts][x_Cs][2]).  On return, if want_stats, `stats` holds those of y (*y_nparts, Cs = C).
+// tape != null: training forward -- the convs store their PRE-activation outputs (u1 = conv0 + temb, u2 = conv1 + bias)
+// in the tape and the consumers apply SiLU while loading; the result is the same function of the same inputs.
 static int run_resblock(int dtype, int C, const void* x, void* y, const float* temb, int temb_stride, const RBPtrs& p,
                         void* h1, void* h2, float* stats, float* scale, float* shift, int x_nparts, int x_Cs,
-                        bool want_stats, int* y_nparts, int B, int H, int W, hipStream_t s) {
+                        bool want_stats, int* y_nparts, int B, int H, int W, hipStream_t s, const RBTape* tape = nullptr) {
     const double cnt = (double)H * W * (C / kGroups);
     const float eps = 1e-6f;
     int np = 0, cs = 0;
-    HIPCHK(gn_finalize_launch(stats, x_nparts, x_Cs, C, cnt, p.g0, p.b0, eps, scale, shift, B, s));
-    ConvCall k1 = {dtype, CONV3, C, C, x, p.w0, nullptr, temb, temb_stride, scale, shift, XF_AFFINE_SILU, 1,
+    float *sc0 = scale, *sh0 = shift, *sc1 = scale, *sh1 = shift, *sc2 = scale, *sh2 = shift;
+    float *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;
+    if (tape) {
+        sc0 = tape->sc(0, B, C); sh0 = tape->sh(0, B, C); sc1 = tape->sc(1, B, C); sh1 = tape->sh(1, B, C);
+        sc2 = tape->sc(2, B, C); sh2 = tape->sh(2, B, C);
+        mr0 = tape->mr(0, B, C); mr1 = tape->mr(1, B, C); mr2 = tape->mr(2, B, C);
+        h1 = tape->u1; h2 = tape->u2;
+    }
+    const int act = tape ? 2 : 1;
+    HIPCHK(gn_finalize_launch(stats, x_nparts, x_Cs, C, cnt, p.g0, p.b0, eps, sc0, sh0, B, s, mr0));
+    ConvCall k1 = {dtype, CONV3, C, C, x, p.w0, nullptr, temb, temb_stride, sc0, sh0, XF_AFFINE_SILU, act,
                    nullptr, h1, stats, B, H, W};
     CHK(run_conv(k1, s, &np, &cs));
-    HIPCHK(gn_finalize_launch(stats, np, cs, C, cnt, p.g1, p.b1, eps, scale, shift, B, s));
-    ConvCall k2 = {dtype, CONV3, C, C, h1, p.w1, p.bias1, nullptr, 0, scale, shift, XF_AFFINE, 1,
+    HIPCHK(gn_finalize_launch(stats, np, cs, C, cnt, p.g1, p.b1, eps, sc1, sh1, B, s, mr1));
+    ConvCall k2 = {dtype, CONV3, C, C, h1, p.w1, p.bias1, nullptr, 0, sc1, sh1, tape ? XF_SILU_AFFINE : XF_AFFINE, act,
                    nullptr, h2, stats, B, H, W};
     CHK(run_conv(k2, s, &np, &cs));
-    HIPCHK(gn_finalize_launch(stats, np, cs, C, cnt, p.g2, nullptr, eps, scale, shift, B, s));
-    HIPCHK(resid_launch(dtype, x, h2, 0, scale, shift, y, want_stats ? stats : nullptr, B, H * W, C, s));
+    HIPCHK(gn_finalize_launch(stats, np, cs, C, cnt, p.g2, nullptr, eps, sc2, sh2, B, s, mr2));
+    HIPCHK(resid_launch(dtype, x, h2, tape ? 2 : 0, sc2, sh2, y, want_stats ? stats : nullptr, B, H * W, C, s));
     if (y_nparts) *y_nparts = resid_nparts(dtype, H * W, C);
+    return 0;
+}
+
+// ---- weight gradient of one convolution: MFMA partial slabs + fixed-order reduction into dst[co][ci][taps] ----
+static void wgrad_plan(const WgradGeom& g, int B, int Hd, int Wd, int* tiles_x, int* tiles_y, int* nsplit, int* per) {
+    *tiles_x = cdiv(Wd, g.tw);
+    *tiles_y = cdiv(Hd, g.th);
+    const int total = B * *tiles_x * *tiles_y;
+    int want = 512 / g.grid_y;
+    if (want < 1) want = 1;
+    if (want > total) want = total;
+    *per = cdiv(total, want);
+    *nsplit = cdiv(total, *per);
+}
+static size_t wgrad_partial_floats(int dtype, int mode, int ci, int co, int B, int Hd, int Wd) {
+    WgradGeom g;
+    if (wgrad_geometry(dtype, mode, ci, co, &g) != hipSuccess) return 0;
+    int tx, ty, ns, per;
+    wgrad_plan(g, B, Hd, Wd, &tx, &ty, &ns, &per);
+    return (size_t)ns * g.ntaps * co * ci;
+}
+// a: [B][Ha][Wa][ci] (halo operand, transformed by xf), du: [B][Hd][Wd][co]; dst fp32 [co][ci][taps]
+static int run_wgrad(int dtype, int mode, int ci, int co, const void* a_t, const void* du, const float* a_scale,
+                     const float* a_shift, int xf, float* partial, float* dst, int B, int Hd, int Wd, hipStream_t s) {
+    WgradGeom g;
+    if (wgrad_geometry(dtype, mode, ci, co, &g) != hipSuccess)
+        return fail("weight gradient %d x %d mode %d dtype %d: no kernel", ci, co, mode, dtype);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = a_t; a.du = du; a.a_scale = a_scale; a.a_shift = a_shift; a.xf = xf; a.partial = partial;
+    a.B = B; a.Hd = Hd; a.Wd = Wd;
+    a.Ha = mode == DOWN4 ? 2 * Hd : Hd;
+    a.Wa = mode == DOWN4 ? 2 * Wd : Wd;
+    int ns;
+    wgrad_plan(g, B, Hd, Wd, &a.tiles_x, &a.tiles_y, &ns, &a.tiles_per_wg);
+    a.total_tiles = B * a.tiles_x * a.tiles_y;
+    HIPCHK(wgrad_launch(dtype, mode, ci, co, a, ns, s));
+    HIPCHK(wgrad_reduce_launch(partial, ns, g.ntaps, co, ci, dst, s));
+    return 0;
+}
+
+// Gradient destinations of one Residual_Block (fp32, the parameters' own layouts); dtemb: [B][stride] slice.
+struct RBGrads {
+    float *g0, *b0, *g1, *b1, *g2, *w0, *w1, *bias1;
+    float* dtemb; int dtemb_stride;
+};
+// Scratch of the block backward (carved by the caller)
+struct RBBwdWs {
+    void *du, *dg;          // activation-sized
+    float *stats, *coef, *dgb, *sums, *partial;
+};
+static size_t rb_bwd_stats_floats(int dtype, int B, int HW, int C) { return (size_t)B * resid_nparts(dtype, HW, C) * C * 2; }
+
+// Backward of Residual_Block (autograd of models/diffusion.py:42-56).  dy -> dx (+ extra if given); parameter
+// gradients are WRITTEN (not accumulated).  wd0 / wd1: data-gradient packings of conv.0 / conv.1.
+static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, const void* dy, const void* extra, void* dx,
+                            const float* gam0, const float* gam1, const float* gam2, const void* wd0, const void* wd1,
+                            const RBGrads& gr, const RBBwdWs& w, int B, int H, int W, hipStream_t s) {
+    const int HW = H * W;
+    const double cnt = (double)HW * (C / kGroups);
+    const int np = resid_nparts(dtype, HW, C);
+    // ---- GN2 (fed by SiLU(u2), weight only) and the SiLU in front of it: du2
+    HIPCHK(gn_bwd_stats_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.stats, B, HW, C, s));
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam2, tp.mr(2, B, C), w.coef, w.dgb, B, s));
+    HIPCHK(colsum_launch(w.dgb, B, 2 * C, C, gr.g2, s));
+    HIPCHK(gn_bwd_apply_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.coef, nullptr, nullptr, w.du, w.sums, B, HW, C, s));
+    HIPCHK(partsum_launch(w.sums, B, np, C, w.dgb, C, s));          // per-sample channel sums of du2
+    HIPCHK(colsum_launch(w.dgb, B, C, C, gr.bias1, s));            // conv.1.bias
+    // ---- conv.1: weight gradient against GN1(SiLU(u1)), data gradient -> dg
+    CHK(run_wgrad(dtype, CONV3, C, C, tp.u1, w.du, tp.sc(1, B, C), tp.sh(1, B, C), XF_SILU_AFFINE, w.partial, gr.w1, B, H, W, s));
+    ConvCall d1 = {dtype, CONV3, C, C, w.du, wd1, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
+    CHK(run_conv(d1, s, nullptr, nullptr));
+    // ---- GN1 (fed by SiLU(u1)) and the SiLU in front of it: du1
+    HIPCHK(gn_bwd_stats_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.stats, B, HW, C, s));
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam1, tp.mr(1, B, C), w.coef, w.dgb, B, s));
+    HIPCHK(colsum_launch(w.dgb, B, 2 * C, C, gr.g1, s));
+    HIPCHK(colsum_launch(w.dgb + C, B, 2 * C, C, gr.b1, s));
+    HIPCHK(gn_bwd_apply_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.coef, nullptr, nullptr, w.du, w.sums, B, HW, C, s));
+    if (gr.dtemb) HIPCHK(partsum_launch(w.sums, B, np, C, gr.dtemb, gr.dtemb_stride, s));  // timestep-embedding chunk
+    // ---- conv.0: weight gradient against SiLU(GN0(x)), data gradient -> dg
+    CHK(run_wgrad(dtype, CONV3, C, C, x, w.du, tp.sc(0, B, C), tp.sh(0, B, C), XF_AFFINE_SILU, w.partial, gr.w0, B, H, W, s));
+    ConvCall d0 = {dtype, CONV3, C, C, w.du, wd0, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
+    CHK(run_conv(d0, s, nullptr, nullptr));
+    // ---- SiLU behind GN0, GN0 itself, and the identity path
+    HIPCHK(gn_bwd_stats_launch(dtype, 1, w.dg, x, tp.sc(0, B, C), tp.sh(0, B, C), w.stats, B, HW, C, s));
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam0, tp.mr(0, B, C), w.coef, w.dgb, B, s));
+    HIPCHK(colsum_launch(w.dgb, B, 2 * C, C, gr.g0, s));
+    HIPCHK(colsum_launch(w.dgb + C, B, 2 * C, C, gr.b0, s));
+    HIPCHK(gn_bwd_apply_launch(dtype, 1, w.dg, x, dy, extra, w.coef, tp.sc(0, B, C), tp.sh(0, B, C), dx, nullptr, B, HW, C, s));
     return 0;
 }
 
@@ -650,6 +763,58 @@ int ddimx_resblock_fwd(int dtype, int C, const void* x, void* y, const float* te
     RBPtrs p = {gn0_w, gn0_b, gn1_w, gn1_b, gn2_w, bias1, w0, w1};
     return run_resblock(dtype, C, x, y, temb, temb_stride, p, o.h1, o.h2, o.stats, o.scale, o.shift,
                         resid_nparts(dtype, H * W, C), C, false, nullptr, B, H, W, s);
+}
+// ---- training: Residual_Block forward that keeps its tape, and its backward --------------------------
+long long ddimx_rb_tape_floats(int B, int C) { return (long long)rb_tape_small_floats(B, C); }
+int ddimx_pack_conv_dgrad(int dtype, const float* w, void* dst, int O, int I, void* stream) {
+    HIPCHK(pack_conv_dgrad_launch(dtype, w, dst, O, I, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_resblock_fwd_train(int dtype, int C, const void* x, void* y, const float* temb, int temb_stride, const float* gn0_w,
+                             const float* gn0_b, const void* w0, const float* gn1_w, const float* gn1_b, const void* w1,
+                             const float* bias1, const float* gn2_w, void* u1, void* u2, float* tape_small, void* workspace,
+                             int B, int H, int W, void* stream) {
+    if (!x || !y || !workspace || !u1 || !u2 || !tape_small) return fail("ddimx_resblock_fwd_train: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    OpWs o;
+    carve_op((char*)workspace, dtype, B, C, H, W, &o);
+    HIPCHK(tensor_stats_launch(dtype, x, o.stats, B, H * W, C, s));
+    RBPtrs p = {gn0_w, gn0_b, gn1_w, gn1_b, gn2_w, bias1, w0, w1};
+    RBTape tp = {u1, u2, tape_small};
+    return run_resblock(dtype, C, x, y, temb, temb_stride, p, nullptr, nullptr, o.stats, o.scale, o.shift,
+                        resid_nparts(dtype, H * W, C), C, false, nullptr, B, H, W, s, &tp);
+}
+static void carve_rb_bwd(char* base, int dtype, int B, int C, int H, int W, RBBwdWs* w, size_t* total) {
+    Carver cv{base, 0};
+    const size_t act = (size_t)B * H * W * C * esz(dtype);
+    w->du = cv.take(act);
+    w->dg = cv.take(act);
+    w->stats = (float*)cv.take(rb_bwd_stats_floats(dtype, B, H * W, C) * 4);
+    w->coef = (float*)cv.take((size_t)B * 3 * C * 4);
+    w->dgb = (float*)cv.take((size_t)B * 2 * C * 4);
+    w->sums = (float*)cv.take((size_t)B * resid_nparts(dtype, H * W, C) * C * 4);
+    w->partial = (float*)cv.take(wgrad_partial_floats(dtype, CONV3, C, C, B, H, W) * 4);
+    *total = cv.off;
+}
+long long ddimx_resblock_bwd_workspace_bytes(int dtype, int B, int C, int H, int W) {
+    RBBwdWs w;
+    size_t total;
+    carve_rb_bwd(nullptr, dtype, B, C, H, W, &w, &total);
+    return (long long)total;
+}
+int ddimx_resblock_bwd(int dtype, int C, const void* x, const void* u1, const void* u2, const float* tape_small,
+                       const void* dy, void* dx, const float* gn0_w, const float* gn1_w, const float* gn2_w,
+                       const void* w0_dgrad, const void* w1_dgrad, float* d_gn0_w, float* d_gn0_b, float* d_w0,
+                       float* d_gn1_w, float* d_gn1_b, float* d_w1, float* d_bias1, float* d_gn2_w, float* d_temb,
+                       int d_temb_stride, void* workspace, int B, int H, int W, void* stream) {
+    if (!x || !u1 || !u2 || !tape_small || !dy || !dx || !workspace) return fail("ddimx_resblock_bwd: null argument");
+    RBBwdWs w;
+    size_t total;
+    carve_rb_bwd((char*)workspace, dtype, B, C, H, W, &w, &total);
+    RBTape tp = {const_cast<void*>(u1), const_cast<void*>(u2), const_cast<float*>(tape_small)};
+    RBGrads gr = {d_gn0_w, d_gn0_b, d_gn1_w, d_gn1_b, d_gn2_w, d_w0, d_w1, d_bias1, d_temb, d_temb_stride};
+    return run_resblock_bwd(dtype, C, x, tp, dy, nullptr, dx, gn0_w, gn1_w, gn2_w, w0_dgrad, w1_dgrad, gr, w, B, H, W,
+                            (hipStream_t)stream);
 }
 int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const float* bias, const float* chan_add,
                       int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,

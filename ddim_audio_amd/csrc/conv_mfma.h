@@ -31,7 +31,8 @@
 namespace ddimx {
 
 enum ConvMode { CONV3 = 0, DOWN4 = 1, UP4 = 2 };
-enum { XF_NONE = 0, XF_AFFINE = 1, XF_AFFINE_SILU = 2 };
+// input transforms applied while the halo is staged: y = x*scale+shift, SiLU(x*scale+shift), SiLU(x)*scale+shift
+enum { XF_NONE = 0, XF_AFFINE = 1, XF_AFFINE_SILU = 2, XF_SILU_AFFINE = 3 };
 
 struct ConvArgs {
     const void* in;         // [B][Hin][Win][CIN]
@@ -45,7 +46,7 @@ struct ConvArgs {
     float* stats;           // [B][nparts][NOUT][2] partial (sum, sumsq) or null
     int chan_add_stride;
     int xf;                 // XF_*
-    int act;                // 0 none, 1 SiLU
+    int act;                // 0 none, 1 SiLU, 2 store the pre-activation but take the statistics of SiLU(value) (training)
     int B, Hin, Win;
     int Hv, Wv;             // virtual output grid (UP4: = input grid; else = output grid)
     int tiles_x, tiles_y;
@@ -339,6 +340,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
             Pairs<T>::unpack(v, f);
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
+                if (XF == XF_SILU_AFFINE) f[j] = silu2(f[j]);
                 f[j] = fma2(f[j], sc[j], sh[j]);
                 if (XF == XF_AFFINE_SILU) f[j] = silu2(f[j]);
             }
@@ -391,6 +393,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     };
     auto halo_commit = [&](int t) __attribute__((always_inline)) {
         if (a.xf == XF_AFFINE_SILU) halo_commit_xf(std::integral_constant<int, XF_AFFINE_SILU>(), t);
+        else if (a.xf == XF_SILU_AFFINE) halo_commit_xf(std::integral_constant<int, XF_SILU_AFFINE>(), t);
         else if (a.xf == XF_AFFINE) halo_commit_xf(std::integral_constant<int, XF_AFFINE>(), t);
         else halo_commit_xf(std::integral_constant<int, XF_NONE>(), t);
     };
@@ -522,7 +525,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
                 }
             }
         };
-        if (a.act) epi1(std::integral_constant<int, 1>()); else epi1(std::integral_constant<int, 0>());
+        if (a.act == 1) epi1(std::integral_constant<int, 1>()); else epi1(std::integral_constant<int, 0>());
         DDIMX_STAMP_AT(3);
         if (C::SEPARATE_OUT && t + 1 < t_end) halo_commit(t + 1);  // halo region is free: stage the next tile now
         DDIMX_STAMP_AT(4);
@@ -532,9 +535,10 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
         // ---- epilogue 2: coalesced stores of whole pixel rows, + skip, per-channel statistics --------------
         // FULL tiles (entirely inside the image) need no per-lane validity; ragged ones drop stores through the
         // buffer bounds check and mask their statistics.
-        auto epi2 = [&](auto full_tag, auto skip_tag) __attribute__((always_inline)) {
+        auto epi2 = [&](auto full_tag, auto skip_tag, auto ssilu_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
             constexpr bool SKIP = decltype(skip_tag)::value;
+            constexpr bool SSILU = decltype(ssilu_tag)::value;  // statistics of SiLU(stored value)
             constexpr int STEP = C::NTHREADS / C::OLPP;          // pixels per pass
             constexpr int NPASS = (C::P + STEP - 1) / STEP;
             if (!ovalid) return;
@@ -573,6 +577,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
                 const float msk = vld[k] ? 1.f : 0.f;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
+                    if (SSILU) f[j] = silu2(f[j]);
                     if (!FULL) f[j] *= msk;
                     st_s[j] += f[j];
                     st_q[j] = fma2(f[j], f[j], st_q[j]);
@@ -581,8 +586,9 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
         };
         {
             const bool full = y0 + C::TH <= a.Hv && x0 + C::TW <= a.Wv;  // wave-uniform
-            if (a.skip) { if (full) epi2(std::true_type(), std::true_type()); else epi2(std::false_type(), std::true_type()); }
-            else { if (full) epi2(std::true_type(), std::false_type()); else epi2(std::false_type(), std::false_type()); }
+            if (a.act == 2) { if (full) epi2(std::true_type(), std::false_type(), std::true_type()); else epi2(std::false_type(), std::false_type(), std::true_type()); }
+            else if (a.skip) { if (full) epi2(std::true_type(), std::true_type(), std::false_type()); else epi2(std::false_type(), std::true_type(), std::false_type()); }
+            else { if (full) epi2(std::true_type(), std::false_type(), std::false_type()); else epi2(std::false_type(), std::false_type(), std::false_type()); }
         }
         DDIMX_STAMP_AT(6);
         if (!C::SEPARATE_OUT && t + 1 < t_end) {

@@ -18,10 +18,11 @@ hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float*
 // stats [B][nparts][Cs][2]; channel vc of the slab is real channel vc % C.  count = elements per group.
 hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, double count, const float* gamma,
                               const float* beta /*nullable*/, float eps, float* scale, float* shift, int B,
-                              hipStream_t s);
+                              hipStream_t s, float* mean_rstd_out /*[B][8][2], nullable*/ = nullptr);
 
 // ---- residual pass: y = x + (h*scale + shift)  (block tail, models/diffusion.py:54-56), or y = x + h ----
-// h_f32: h is fp32 (FNet output) and no affine is applied.  stats nullable.  Elements per sample = HW*C.
+// h_f32 = 1: h is fp32 (FNet output) and no affine is applied; h_f32 = 2: y = x + SiLU(h)*scale + shift (training
+// forward, h = pre-activation).  stats nullable.  Elements per sample = HW*C.
 hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, const float* scale, const float* shift,
                         void* y, float* stats, int B, int HW, int C, hipStream_t s);
 int resid_nparts(int dtype, int HW, int C);

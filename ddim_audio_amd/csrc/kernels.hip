@@ -300,7 +300,8 @@ hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float*
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ stats, int nparts, int Cs, int C,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mr_out) {
     __shared__ double rs[4], rq[4];
     __shared__ float mr[2];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -324,6 +325,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
         if (var < 0.0) var = 0.0;
         mr[0] = (float)mean;
         mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mr_out) {  // saved for the backward pass: [B][groups][2] = (mean, rstd)
+            mr_out[((size_t)b * kGroups + g) * 2 + 0] = mr[0];
+            mr_out[((size_t)b * kGroups + g) * 2 + 1] = mr[1];
+        }
     }
     __syncthreads();
     for (int i = tid; i < GS; i += 256) {
@@ -335,10 +340,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
 }
 
 hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, double count, const float* gamma,
-                              const float* beta, float eps, float* scale, float* shift, int B, hipStream_t s) {
+                              const float* beta, float eps, float* scale, float* shift, int B, hipStream_t s, float* mr_out) {
     if (C % kGroups || Cs % C) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(kGroups, B), dim3(256), 0, s, stats, nparts, Cs, C, count, gamma, beta,
-                       eps, scale, shift);
+                       eps, scale, shift, mr_out);
     return hipGetLastError();
 }
 
@@ -355,7 +360,7 @@ int resid_nparts(int dtype, int HW, int C) {
     return (int)((pieces + per_block - 1) / per_block);
 }
 
-template <typename T, bool HF32>
+template <typename T, bool HF32, bool HSILU = false>
 __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __restrict__ hv,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     T* y, float* __restrict__ stats, int HW, int C) {
@@ -391,7 +396,7 @@ __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __re
             Piece<T>::unpack(*(const uint4*)((const T*)hv + e), fh);
         }
 #pragma unroll
-        for (int j = 0; j < EPB; ++j) fx[j] = fx[j] + fmaf(fh[j], sc[j], sh[j]);
+        for (int j = 0; j < EPB; ++j) fx[j] = fx[j] + fmaf(HSILU ? silu_f(fh[j]) : fh[j], sc[j], sh[j]);
         const uint4 pv = Piece<T>::pack(fx);
         *(uint4*)(y + e) = pv;
         Piece<T>::unpack(pv, fx);
@@ -425,7 +430,12 @@ hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, cons
     if (lds > 64 * 1024) return hipErrorInvalidValue;
 #define DDIMX_RESID(TT, HF)                                                                                     \
     hipLaunchKernelGGL((resid_kernel<TT, HF>), grid, dim3(bd), lds, s, (const TT*)x, h, scale, shift, (TT*)y, stats, HW, C)
-    if (dtype == DT_BF16) { if (h_f32) DDIMX_RESID(__bf16, true); else DDIMX_RESID(__bf16, false); }
+    if (h_f32 == 2) {  // training forward: h holds the pre-activation, y = x + SiLU(h)*scale + shift
+        if (dtype == DT_BF16)
+            hipLaunchKernelGGL((resid_kernel<__bf16, false, true>), grid, dim3(bd), lds, s, (const __bf16*)x, h, scale, shift, (__bf16*)y, stats, HW, C);
+        else
+            hipLaunchKernelGGL((resid_kernel<float, false, true>), grid, dim3(bd), lds, s, (const float*)x, h, scale, shift, (float*)y, stats, HW, C);
+    } else if (dtype == DT_BF16) { if (h_f32) DDIMX_RESID(__bf16, true); else DDIMX_RESID(__bf16, false); }
     else { if (h_f32) DDIMX_RESID(float, true); else DDIMX_RESID(float, false); }
 #undef DDIMX_RESID
     return hipGetLastError();

@@ -105,6 +105,26 @@ int ddimx_resblock_fwd(int dtype, int C, const void* x, void* y, const float* te
                        const float* gn0_w, const float* gn0_b, const void* w0, const float* gn1_w,
                        const float* gn1_b, const void* w1, const float* bias1, const float* gn2_w, void* workspace,
                        int B, int H, int W, void* stream);
+/* ---- training (autograd of the same reference code: runners/diffusion.py:150 `loss.backward()`) ----
+ * Residual_Block forward that keeps what its backward needs: u1 = conv.0(...) + temb and u2 = conv.1(...) + bias
+ * (PRE-activation, NHWC [B][H][W][C] in the activation dtype) and tape_small (ddimx_rb_tape_floats(B, C) floats:
+ * folded GroupNorm scale/shift and (mean, rstd) of the three norms).  Same result as ddimx_resblock_fwd. */
+long long ddimx_rb_tape_floats(int B, int C);
+int ddimx_resblock_fwd_train(int dtype, int C, const void* x, void* y, const float* temb, int temb_stride,
+                             const float* gn0_w, const float* gn0_b, const void* w0, const float* gn1_w,
+                             const float* gn1_b, const void* w1, const float* bias1, const float* gn2_w, void* u1,
+                             void* u2, float* tape_small, void* workspace, int B, int H, int W, void* stream);
+/* data-gradient packing of a 3x3 Conv2d.weight [O][I][3][3]: dst[tap][I][O] = w[.., 8 - tap] (activation dtype) */
+int ddimx_pack_conv_dgrad(int dtype, const float* w, void* dst, int O, int I, void* stream);
+/* Backward of Residual_Block (models/diffusion.py:42-56): dy -> dx and the gradients of its 8 parameters (fp32, the
+ * parameters' own shapes, WRITTEN not accumulated) and of its timestep-embedding chunk d_temb [B][d_temb_stride]
+ * (nullable).  workspace: ddimx_resblock_bwd_workspace_bytes(). */
+long long ddimx_resblock_bwd_workspace_bytes(int dtype, int B, int C, int H, int W);
+int ddimx_resblock_bwd(int dtype, int C, const void* x, const void* u1, const void* u2, const float* tape_small,
+                       const void* dy, void* dx, const float* gn0_w, const float* gn1_w, const float* gn2_w,
+                       const void* w0_dgrad, const void* w1_dgrad, float* d_gn0_w, float* d_gn0_b, float* d_w0,
+                       float* d_gn1_w, float* d_gn1_b, float* d_w1, float* d_bias1, float* d_gn2_w, float* d_temb,
+                       int d_temb_stride, void* workspace, int B, int H, int W, void* stream);
 /* One fused 3x3 convolution of a Residual_Block (models/diffusion.py:28-40,46-53): the GroupNorm
  * affine (xf = 1) or affine + SiLU (xf = 2) folded as per-(sample, channel) scale/shift [B][C] is applied
  * to the input while it is staged; epilogue adds bias [C] and chan_add [B][chan_add_stride] (either may

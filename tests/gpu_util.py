@@ -101,3 +101,44 @@ def check_close(got, want, dt, what="", scale=1.0):
     tol = TOL[dt]
     assert mx <= tol["mx"] * scale and rms <= tol["rms"] * scale, f"{what}: max {mx:.3e} rms {rms:.3e} (rel. to std) exceeds {tol}"
     return mx, rms
+
+
+# ---- training ops ------------------------------------------------------------------------------------
+def pack_conv_dgrad(w, dt):
+    lib = _lib.load()
+    w = w.to(dev(), torch.float32).contiguous()
+    o, i = w.shape[0], w.shape[1]
+    dst = torch.empty(9 * o * i, dtype=TORCH_DT[dt], device=dev())
+    _lib.check(lib.ddimx_pack_conv_dgrad(dt, _lib.ptr(w), _lib.ptr(dst), o, i, _lib.stream()))
+    return dst
+
+
+def resblock_train(sd, p, x, temb, dy, dt):
+    """Training forward + backward of one Residual_Block: returns (y, dx, {param: grad}, dtemb), all on the CPU."""
+    lib = _lib.load()
+    b, c, h, w = x.shape
+    xn, dyn = to_nhwc(x, dt), to_nhwc(dy, dt)
+    yn, u1, u2, dxn = (torch.empty_like(xn) for _ in range(4))
+    small = torch.empty(int(lib.ddimx_rb_tape_floats(b, c)), dtype=torch.float32, device=dev())
+    ws = torch.empty(int(lib.ddimx_op_workspace_bytes(dt, b, c, h, w)), dtype=torch.uint8, device=dev())
+    names = ("norm.0.weight", "norm.0.bias", "norm.1.weight", "norm.1.bias", "norm.2.weight", "conv.1.bias")
+    k = {n: g(sd[p + n]) for n in names}
+    w0, w1 = pack_conv(sd[p + "conv.0.weight"], dt), pack_conv(sd[p + "conv.1.weight"], dt)
+    tg = g(temb)
+    _lib.check(lib.ddimx_resblock_fwd_train(dt, c, _lib.ptr(xn), _lib.ptr(yn), _lib.ptr(tg), tg.shape[1], _lib.ptr(k["norm.0.weight"]),
+                                            _lib.ptr(k["norm.0.bias"]), _lib.ptr(w0), _lib.ptr(k["norm.1.weight"]),
+                                            _lib.ptr(k["norm.1.bias"]), _lib.ptr(w1), _lib.ptr(k["conv.1.bias"]),
+                                            _lib.ptr(k["norm.2.weight"]), _lib.ptr(u1), _lib.ptr(u2), _lib.ptr(small), _lib.ptr(ws),
+                                            b, h, w, _lib.stream()))
+    wd0, wd1 = pack_conv_dgrad(sd[p + "conv.0.weight"], dt), pack_conv_dgrad(sd[p + "conv.1.weight"], dt)
+    grads = {n: torch.full(tuple(sd[p + n].shape), float("nan"), device=dev()) for n in names + ("conv.0.weight", "conv.1.weight")}
+    dtemb = torch.full((b, c), float("nan"), device=dev())
+    bws = torch.empty(int(lib.ddimx_resblock_bwd_workspace_bytes(dt, b, c, h, w)), dtype=torch.uint8, device=dev())
+    _lib.check(lib.ddimx_resblock_bwd(dt, c, _lib.ptr(xn), _lib.ptr(u1), _lib.ptr(u2), _lib.ptr(small), _lib.ptr(dyn), _lib.ptr(dxn),
+                                      _lib.ptr(k["norm.0.weight"]), _lib.ptr(k["norm.1.weight"]), _lib.ptr(k["norm.2.weight"]),
+                                      _lib.ptr(wd0), _lib.ptr(wd1), _lib.ptr(grads["norm.0.weight"]), _lib.ptr(grads["norm.0.bias"]),
+                                      _lib.ptr(grads["conv.0.weight"]), _lib.ptr(grads["norm.1.weight"]), _lib.ptr(grads["norm.1.bias"]),
+                                      _lib.ptr(grads["conv.1.weight"]), _lib.ptr(grads["conv.1.bias"]), _lib.ptr(grads["norm.2.weight"]),
+                                      _lib.ptr(dtemb), c, _lib.ptr(bws), b, h, w, _lib.stream()))
+    torch.cuda.synchronize()
+    return from_nhwc(yn, dt), from_nhwc(dxn, dt), {n: v.cpu() for n, v in grads.items()}, dtemb.cpu()
