@@ -2,7 +2,7 @@
 or a call fails, a RuntimeError is raised (the reference's ``main.py:212-223`` logs exceptions)."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_longlong, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_longlong, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DDIMX_LIB", os.path.join(_HERE, "libddimx.so"))
@@ -36,6 +36,17 @@ _SIGS = {
     "ddimx_pack_weights": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "ddimx_unet_fwd": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_void_p]),
+    "ddimx_packed_bwd_bytes": (c_longlong, [c_void_p]),
+    "ddimx_pack_weights_bwd": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p]),
+    "ddimx_train_tape_bytes": (c_longlong, [c_void_p, c_int, c_int]),
+    "ddimx_train_workspace_bytes": (c_longlong, [c_void_p, c_int, c_int]),
+    "ddimx_grad_floats": (c_longlong, [c_void_p]),
+    "ddimx_grad_offset": (c_longlong, [c_void_p, c_int]),
+    "ddimx_unet_fwd_train": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, c_void_p]),
+    "ddimx_unet_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, c_void_p]),
+    "ddimx_sqerr_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     "ddimx_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_from_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_pack_conv": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

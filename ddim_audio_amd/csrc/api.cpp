@@ -714,6 +714,543 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
     return 0;
 }
 
+// ======================================================================================================
+// Training: forward that keeps a tape, and the whole-network backward.
+// (reference: functions/losses.py:12-18 builds the graph, runners/diffusion.py:150 `loss.backward()` walks it)
+// ======================================================================================================
+}  // extern "C"
+
+// Extra weight packings the backward needs: data-gradient layouts of the convs and transposed FNet matrices.
+struct BwdPack {
+    std::vector<std::vector<size_t>> dn_wd0, dn_wd1, up_wd0, up_wd1;  // [level][r] offsets
+    std::vector<size_t> down_dg, up_dg;                              // per level (level 0 unused)
+    size_t projT, coutT;
+    std::vector<size_t> w1T, w2T;
+    size_t total;
+};
+static void plan_bwd_pack(const ddimx_ctx* c, BwdPack* b) {
+    const ddimx_config& f = c->cfg;
+    const int L = c->L;
+    const size_t es = esz(c->dtype);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
+    b->dn_wd0.assign(L, {}); b->dn_wd1.assign(L, {}); b->up_wd0.assign(L, {}); b->up_wd1.assign(L, {});
+    b->down_dg.assign(L, 0); b->up_dg.assign(L, 0);
+    for (int l = 0; l < L; ++l) {
+        const size_t cc = (size_t)9 * f.ch[l] * f.ch[l] * es;
+        for (int r = 0; r < f.res[l]; ++r) {
+            b->dn_wd0[l].push_back(take(cc)); b->dn_wd1[l].push_back(take(cc));
+            b->up_wd0[l].push_back(take(cc)); b->up_wd1[l].push_back(take(cc));
+        }
+        if (l > 0) {
+            b->down_dg[l] = take((size_t)2 * 6 * 2 * f.ch[l - 1] * f.ch[l] * es);  // Conv2d weight read as ConvTranspose2d [I=C][O=Cprev]
+            b->up_dg[l] = take((size_t)16 * f.ch[l] * f.ch[l - 1] * es);           // ConvTranspose2d weight read as Conv2d [O=C][I=Cprev]
+        }
+    }
+    const size_t hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width;
+    b->projT = take(width * hid * 4);
+    b->coutT = take(hid * width * 4);
+    for (int i = 0; i < f.fnet_layers; ++i) { b->w1T.push_back(take(hid * inter * 4)); b->w2T.push_back(take(inter * hid * 4)); }
+    b->total = off;
+}
+
+// What the training forward keeps (carved from the caller's `tape` buffer; depends on B and T).
+struct TrainTape {
+    float *temb_h1p, *temb_h2p, *temb;
+    void* A;
+    std::vector<void*> dn_in, up_in;
+    std::vector<std::vector<RBTape>> dn_rb, up_rb;
+    std::vector<std::vector<void*>> dn_y, up_y;
+    float *ln0, *ln0_stat, *X0;
+    struct FLT { float *Z, *zstat, *Y1, *pre, *s, *sstat, *Xout; };
+    std::vector<FLT> fl;
+    size_t total;
+};
+static void carve_tape(const ddimx_ctx* c, char* base, int B, int T, TrainTape* t) {
+    const ddimx_config& f = c->cfg;
+    const int L = c->L;
+    const size_t es = esz(c->dtype);
+    Carver cv{base, 0};
+    t->temb_h1p = (float*)cv.take((size_t)B * 512 * 4);
+    t->temb_h2p = (float*)cv.take((size_t)B * 512 * 4);
+    t->temb = (float*)cv.take((size_t)B * c->E * 4);
+    t->A = cv.take((size_t)B * T * f.f_size * f.ch[0] * es);
+    t->dn_in.assign(L, nullptr); t->up_in.assign(L, nullptr);
+    t->dn_rb.assign(L, {}); t->up_rb.assign(L, {}); t->dn_y.assign(L, {}); t->up_y.assign(L, {});
+    for (int l = 0; l < L; ++l) {
+        const size_t act = (size_t)B * (T >> l) * (f.f_size >> l) * f.ch[l] * es;
+        t->dn_in[l] = l == 0 ? t->A : cv.take(act);
+        t->up_in[l] = cv.take(act);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int r = 0; r < f.res[l]; ++r) {
+                RBTape rb;
+                rb.u1 = cv.take(act); rb.u2 = cv.take(act);
+                rb.small = (float*)cv.take(rb_tape_small_floats(B, f.ch[l]) * 4);
+                (pass ? t->up_rb : t->dn_rb)[l].push_back(rb);
+                (pass ? t->up_y : t->dn_y)[l].push_back(cv.take(act));
+            }
+    }
+    const int S = T >> (L - 1);
+    const size_t M = (size_t)B * S, hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width;
+    t->ln0 = (float*)cv.take(M * width * 4);
+    t->ln0_stat = (float*)cv.take(M * 2 * 4);
+    t->X0 = (float*)cv.take(M * hid * 4);
+    t->fl.clear();
+    for (int i = 0; i < f.fnet_layers; ++i) {
+        TrainTape::FLT q;
+        q.Z = (float*)cv.take(M * hid * 4); q.zstat = (float*)cv.take(M * 2 * 4);
+        q.Y1 = (float*)cv.take(M * hid * 4); q.pre = (float*)cv.take(M * inter * 4);
+        q.s = (float*)cv.take(M * hid * 4); q.sstat = (float*)cv.take(M * 2 * 4);
+        q.Xout = (float*)cv.take(M * hid * 4);
+        t->fl.push_back(q);
+    }
+    t->total = cv.off;
+}
+
+// Scratch shared by the training forward and the backward.
+struct TrainWs {
+    float *stats, *scale, *shift;
+    float *Ut, *Hb, *O, *gpart;
+    std::vector<void*> Ga, Gb, GS;
+    void *gA, *du, *dg;
+    float *coef, *dgb, *sums, *partial;
+    float *dtemb, *dh2, *dh1;
+    float *dO, *dXa, *dXb, *dZ, *dH, *T1, *T2, *lnpart, *dTok, *pgrad;
+    size_t total;
+};
+static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs* w) {
+    const ddimx_config& f = c->cfg;
+    const int L = c->L, dt = c->dtype;
+    const size_t es = esz(dt);
+    Carver cv{base, 0};
+    size_t stats_f = (size_t)B * conv_in_nparts(T, f.f_size) * f.ch[0] * 2, hmax = 0, part_f = 0, sums_f = 0;
+    int cmax = 0;
+    w->Ga.assign(L, nullptr); w->Gb.assign(L, nullptr); w->GS.assign(L, nullptr);
+    for (int l = 0; l < L; ++l) {
+        const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        const size_t act = (size_t)B * H * W * C * es;
+        w->Ga[l] = cv.take(act); w->Gb[l] = cv.take(act); w->GS[l] = cv.take(act);
+        if (act > hmax) hmax = act;
+        if (C > cmax) cmax = C;
+        size_t q = conv_stats_floats(dt, CONV3, C, C, B, H, W);
+        if (q > stats_f) stats_f = q;
+        q = (size_t)B * resid_nparts(dt, H * W, C) * C * 2;
+        if (q > stats_f) stats_f = q;
+        if (q / 2 > sums_f) sums_f = q / 2;
+        q = wgrad_partial_floats(dt, CONV3, C, C, B, H, W);
+        if (q > part_f) part_f = q;
+        if (l > 0) {
+            q = conv_stats_floats(dt, DOWN4, f.ch[l - 1], C, B, H, W);
+            if (q > stats_f) stats_f = q;
+            q = conv_stats_floats(dt, UP4, C, f.ch[l - 1], B, H, W);
+            if (q > stats_f) stats_f = q;
+            q = wgrad_partial_floats(dt, DOWN4, f.ch[l - 1], C, B, H, W);
+            if (q > part_f) part_f = q;
+        }
+    }
+    {
+        const size_t q = edge_wgrad_partial_floats(B, f.ch[0], f.in_channels, T, f.f_size);
+        if (q > part_f) part_f = q;
+    }
+    w->gA = cv.take((size_t)B * T * f.f_size * f.ch[0] * es);
+    w->du = cv.take(hmax);
+    w->dg = cv.take(hmax);
+    w->stats = (float*)cv.take(stats_f * 4);
+    w->scale = (float*)cv.take((size_t)B * cmax * 4);
+    w->shift = (float*)cv.take((size_t)B * cmax * 4);
+    w->coef = (float*)cv.take((size_t)B * 3 * cmax * 4);
+    w->dgb = (float*)cv.take((size_t)B * 2 * cmax * 4);
+    w->sums = (float*)cv.take(sums_f * 4);
+    w->partial = (float*)cv.take(part_f * 4);
+    w->dtemb = (float*)cv.take((size_t)B * c->E * 4);
+    w->dh2 = (float*)cv.take((size_t)B * 512 * 4);
+    w->dh1 = (float*)cv.take((size_t)B * 512 * 4);
+    const int S = T >> (L - 1);
+    const size_t M = (size_t)B * S, hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width;
+    const size_t big = inter > width ? inter : width;
+    w->Ut = (float*)cv.take((size_t)B * 2 * hid * S * 4);
+    w->Hb = (float*)cv.take(M * inter * 4);
+    w->O = (float*)cv.take(M * width * 4);
+    w->dO = (float*)cv.take(M * width * 4);
+    w->dXa = (float*)cv.take(M * hid * 4);
+    w->dXb = (float*)cv.take(M * hid * 4);
+    w->dZ = (float*)cv.take(M * hid * 4);
+    w->dH = (float*)cv.take(M * inter * 4);
+    w->T1 = (float*)cv.take(M * big * 4);
+    w->T2 = (float*)cv.take(M * big * 4);
+    w->lnpart = (float*)cv.take((size_t)ln_bwd_nblocks((int)M) * 2 * big * 4);
+    w->dTok = (float*)cv.take(M * width * 4);
+    w->pgrad = (float*)cv.take(hid * width * 4);
+    {   // split-K partial tiles: forward shapes and the backward GEMMs (weight gradients contract over M)
+        const int bf = dt == DT_BF16, Mi = (int)M, h = (int)hid, in = (int)inter, wd = (int)width;
+        const int shp[][5] = {{Mi, h, wd, 1, bf}, {2 * h, S, h, B, 0}, {S, h, 2 * S, B, 0}, {Mi, in, h, 1, bf}, {Mi, h, in, 1, bf},
+                              {Mi, wd, h, 1, bf}, {wd, h, Mi, 1, bf}, {h, in, Mi, 1, bf}, {in, h, Mi, 1, bf}, {h, wd, Mi, 1, bf}};
+        size_t mx = 0;
+        for (auto& q : shp) {
+            const size_t n = (size_t)gemm_pick_splitk(q[0], q[1], q[2], q[3], q[4]) * q[3] * q[0] * q[1];
+            if (n > mx) mx = n;
+        }
+        w->gpart = (float*)cv.take(mx * 4);
+    }
+    w->total = cv.off;
+}
+
+// GEMM helper over the training scratch (same call shape as fnet_gemm)
+static int tgemm(const TrainWs& w, hipStream_t s, const float* A, const float* Bm, float* C, int M, int N, int K, const float* bias,
+                 const float* resid, int bf16, int batch = 1, long long sA = 0, long long sB = 0, long long sC = 0, int lda = -1,
+                 int ldb = -1) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = Bm; g.C = C; g.bias = bias; g.resid = resid; g.partial = w.gpart;
+    g.M = M; g.N = N; g.K = K; g.lda = lda < 0 ? K : lda; g.ldb = ldb < 0 ? K : ldb; g.ldc = N;
+    g.sA = sA; g.sB = sB; g.sC = sC; g.batch = batch; g.bf16 = bf16;
+    g.splitk = gemm_pick_splitk(M, N, K, batch, bf16);
+    HIPCHK(gemm_launch(g, s));
+    return 0;
+}
+// Re(FFT2(X)) + X over [B][S][hid] token matrices (linear and symmetric: also its own backward)
+static int fourier_mix(const ddimx_ctx* c, const ddimx_tables* tb, const TrainWs& w, const float* X, float* Z, int B, int S,
+                       hipStream_t s) {
+    const int hid = c->cfg.fnet_hidden;
+    CHK(tgemm(w, s, tb->dft_hidden, X, w.Ut, 2 * hid, S, hid, nullptr, nullptr, 0, B, 0, (long long)S * hid, (long long)2 * hid * S));
+    CHK(tgemm(w, s, tb->dft_seq, w.Ut, Z, S, hid, 2 * S, nullptr, X, 0, B, 0, (long long)2 * hid * S, (long long)S * hid));
+    return 0;
+}
+
+static inline int down_bi(const ddimx_config& f, int l, int r) { int b = 0; for (int i = 0; i < l; ++i) b += f.res[i]; return b + r; }
+static inline int up_bi(const ddimx_config& f, int L, int l, int r) { int b = 0; for (int i = L - 1; i > l; --i) b += f.res[i]; return b + r; }
+
+// per-channel sums of an NHWC tensor over (batch, pixels) -> dst[C]   (bias gradients of Downsample / Upsample)
+static int channel_sums(int dt, const void* x, const TrainWs& w, float* dst, int B, int HW, int C, hipStream_t s) {
+    HIPCHK(tensor_stats_launch(dt, x, w.stats, B, HW, C, s));
+    HIPCHK(partsum_launch(w.stats, B, resid_nparts(dt, HW, C), C, w.dgb, C, s, 2));
+    HIPCHK(colsum_launch(w.dgb, B, C, C, dst, s));
+    return 0;
+}
+
+extern "C" {
+
+long long ddimx_packed_bwd_bytes(ddimx_handle h) {
+    if (!h) return 0;
+    BwdPack b;
+    plan_bwd_pack(h, &b);
+    return (long long)b.total;
+}
+long long ddimx_train_tape_bytes(ddimx_handle h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    TrainTape t;
+    carve_tape(h, nullptr, B, T, &t);
+    return (long long)t.total;
+}
+long long ddimx_train_workspace_bytes(ddimx_handle h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    TrainWs w;
+    carve_train_ws(h, nullptr, B, T, &w);
+    return (long long)w.total;
+}
+long long ddimx_grad_floats(ddimx_handle h) {
+    long long n = 0;
+    if (h) for (auto& p : h->specs) n += (p.numel + 63) & ~63ll;
+    return n;
+}
+long long ddimx_grad_offset(ddimx_handle h, int i) {
+    if (!h || i < 0 || i >= (int)h->specs.size()) return -1;
+    long long n = 0;
+    for (int k = 0; k < i; ++k) n += (h->specs[k].numel + 63) & ~63ll;
+    return n;
+}
+
+int ddimx_pack_weights_bwd(ddimx_handle h, const void* const* params, int n_params, const void* packed, void* packed_bwd,
+                           void* stream) {
+    if (!h || !params || !packed || !packed_bwd) return fail("ddimx_pack_weights_bwd: null argument");
+    if (n_params != (int)h->specs.size()) return fail("ddimx_pack_weights_bwd: got %d tensors, plan has %zu", n_params, h->specs.size());
+    const ddimx_ctx* c = h;
+    const ddimx_config& f = c->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    BwdPack b;
+    plan_bwd_pack(c, &b);
+    char* base = (char*)packed_bwd;
+    const int dt = c->dtype;
+    for (int l = 0; l < c->L; ++l) {
+        const int C = f.ch[l];
+        for (int r = 0; r < f.res[l]; ++r) {
+            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->down_rb[l][r].w0], base + b.dn_wd0[l][r], C, C, s));
+            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->down_rb[l][r].w1], base + b.dn_wd1[l][r], C, C, s));
+            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->up_rb[l][r].w0], base + b.up_wd0[l][r], C, C, s));
+            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->up_rb[l][r].w1], base + b.up_wd1[l][r], C, C, s));
+        }
+        if (l > 0) {
+            // d(input) of Conv2d(W [C][Cprev][4][4], s2 p1) = ConvTranspose2d with the same tensor read as [I = C][O = Cprev]
+            HIPCHK(pack_convT_launch(dt, (const float*)params[c->down_w[l]], base + b.down_dg[l], C, f.ch[l - 1], s));
+            // d(input) of ConvTranspose2d(W [C][Cprev][4][4]) = Conv2d with the same tensor read as [O = C][I = Cprev]
+            HIPCHK(pack_conv_launch(dt, (const float*)params[c->up_w[l]], base + b.up_dg[l], C, f.ch[l - 1], 4, 4, s));
+        }
+    }
+    const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width;
+    HIPCHK(transpose_launch(pf(c, packed, c->proj_w), (float*)(base + b.projT), hid, width, 0, s));   // [hid][width] -> [width][hid]
+    HIPCHK(transpose_launch(pf(c, packed, c->cout_w), (float*)(base + b.coutT), width, hid, 0, s));   // [width][hid] -> [hid][width]
+    for (int i = 0; i < f.fnet_layers; ++i) {
+        HIPCHK(transpose_launch(pf(c, packed, c->fl[i].w1), (float*)(base + b.w1T[i]), inter, hid, 0, s));
+        HIPCHK(transpose_launch(pf(c, packed, c->fl[i].w2), (float*)(base + b.w2T[i]), hid, inter, 0, s));
+    }
+    return 0;
+}
+
+int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace,
+                         long long workspace_bytes, void* tape, long long tape_bytes, const float* x, const int64_t* t, float* eps,
+                         int B, int T, float dropout_p, unsigned long long seed, void* stream) {
+    if (!h || !packed || !tables || !workspace || !tape || !x || !t || !eps) return fail("ddimx_unet_fwd_train: null argument");
+    const ddimx_ctx* c = h;
+    const ddimx_config& f = c->cfg;
+    const int L = c->L, dt = c->dtype;
+    if (B < 1) return fail("batch %d", B);
+    if (T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("T=%d must be a positive multiple of %d", T, 1 << (L - 1));
+    if (dropout_p < 0.f || dropout_p >= 1.f) return fail("dropout probability %g out of [0, 1)", (double)dropout_p);
+    for (int l = 0; l < L; ++l) if (f.res[l] < 1) return fail("training needs at least one residual block per level");
+    TrainWs w;
+    carve_train_ws(c, (char*)workspace, B, T, &w);
+    if ((long long)w.total > workspace_bytes) return fail("training workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
+    TrainTape tp;
+    carve_tape(c, (char*)tape, B, T, &tp);
+    if ((long long)tp.total > tape_bytes) return fail("tape too small: need %zu bytes, got %lld", tp.total, tape_bytes);
+    hipStream_t s = (hipStream_t)stream;
+
+    // timestep embedding, keeping the pre-activations (models/diffusion.py:110-120)
+    HIPCHK(linear_rows_launch(pf(c, packed, c->te), t, pf(c, packed, c->tw[0]), pf(c, packed, c->tb[0]), tp.temb_h1p, B, 512, 128, 0, s));
+    HIPCHK(linear_rows_launch(tp.temb_h1p, nullptr, pf(c, packed, c->tw[1]), pf(c, packed, c->tb[1]), tp.temb_h2p, B, 512, 512, 0, s, 1));
+    HIPCHK(linear_rows_launch(tp.temb_h2p, nullptr, pf(c, packed, c->tw[2]), pf(c, packed, c->tb[2]), tp.temb, B, c->E, 512, 0, s, 1));
+
+    HIPCHK(conv_in_launch(dt, x, pf(c, packed, c->in_w), pf(c, packed, c->in_b), tp.A, w.stats, B, f.in_channels, f.ch[0], T, f.f_size, s));
+    int np = conv_in_nparts(T, f.f_size), cs = f.ch[0];
+    const void* cur = tp.A;
+    for (int l = 0; l < L; ++l) {
+        const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        if (l > 0) {
+            ConvCall d = {dt, DOWN4, f.ch[l - 1], C, cur, pv(c, packed, c->down_w[l]), pf(c, packed, c->down_b[l]), nullptr, 0,
+                          nullptr, nullptr, XF_NONE, 0, nullptr, tp.dn_in[l], w.stats, B, H * 2, W * 2};
+            CHK(run_conv(d, s, &np, &cs));
+            cur = tp.dn_in[l];
+        }
+        for (int r = 0; r < f.res[l]; ++r) {
+            int ynp = 0;
+            CHK(run_resblock(dt, C, cur, tp.dn_y[l][r], tp.temb + c->emb_off_down[down_bi(f, l, r)], c->E,
+                             rb_ptrs(c, packed, c->down_rb[l][r]), nullptr, nullptr, w.stats, w.scale, w.shift, np, cs,
+                             r != f.res[l] - 1, &ynp, B, H, W, s, &tp.dn_rb[l][r]));
+            cur = tp.dn_y[l][r];
+            np = ynp; cs = C;
+        }
+    }
+    // bottleneck (models/diffusion.py:267-279), training mode: dropout after the projection and after each FFN
+    const int S = T >> (L - 1), CL = f.ch[L - 1];
+    const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
+    const float eps_ln = f.fnet_ln_eps;
+    const int bf = dt == DT_BF16;
+    HIPCHK(ln_train_launch(dt, cur, tables->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps_ln, tp.ln0, nullptr,
+                           tp.ln0_stat, M, width, 0.f, seed, 0, s));
+    CHK(tgemm(w, s, tp.ln0, pf(c, packed, c->proj_w), tp.X0, M, hid, width, pf(c, packed, c->proj_b), nullptr, bf));
+    if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(tp.X0, tp.X0, (long long)M * hid, dropout_p, seed, 0, s));
+    const float* xc = tp.X0;
+    for (int i = 0; i < f.fnet_layers; ++i) {
+        const ddimx_ctx::FL& Lw = c->fl[i];
+        const TrainTape::FLT& q = tp.fl[i];
+        CHK(fourier_mix(c, tables, w, xc, q.Z, B, S, s));
+        HIPCHK(ln_train_launch(DT_F32, q.Z, nullptr, 1, pf(c, packed, Lw.ln1_w), pf(c, packed, Lw.ln1_b), eps_ln, q.Y1, nullptr,
+                               q.zstat, M, hid, 0.f, seed, 0, s));
+        CHK(tgemm(w, s, q.Y1, pf(c, packed, Lw.w1), q.pre, M, inter, hid, pf(c, packed, Lw.b1), nullptr, bf));
+        HIPCHK(gelu_launch(q.pre, nullptr, w.Hb, (long long)M * inter, 0, s));
+        CHK(tgemm(w, s, w.Hb, pf(c, packed, Lw.w2), w.dXa, M, hid, inter, pf(c, packed, Lw.b2), nullptr, bf));
+        HIPCHK(ln_train_launch(DT_F32, w.dXa, q.Y1, M, pf(c, packed, Lw.ln2_w), pf(c, packed, Lw.ln2_b), eps_ln, q.Xout, q.s,
+                               q.sstat, M, hid, dropout_p, seed, (unsigned)(i + 1), s));
+        xc = q.Xout;
+    }
+    CHK(tgemm(w, s, xc, pf(c, packed, c->cout_w), w.O, M, width, hid, pf(c, packed, c->cout_b), nullptr, bf));
+    HIPCHK(resid_launch(dt, cur, w.O, 1, nullptr, nullptr, tp.up_in[L - 1], w.stats, B, S * c->Fr, CL, s));
+    np = resid_nparts(dt, S * c->Fr, CL); cs = CL;
+    for (int l = L - 1; l >= 0; --l) {
+        const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        cur = tp.up_in[l];
+        for (int r = 0; r < f.res[l]; ++r) {
+            int ynp = 0;
+            CHK(run_resblock(dt, C, cur, tp.up_y[l][r], tp.temb + c->emb_off_up[up_bi(f, L, l, r)], c->E,
+                             rb_ptrs(c, packed, c->up_rb[l][r]), nullptr, nullptr, w.stats, w.scale, w.shift, np, cs,
+                             r != f.res[l] - 1, &ynp, B, H, W, s, &tp.up_rb[l][r]));
+            cur = tp.up_y[l][r];
+            np = ynp; cs = C;
+        }
+        if (l > 0) {
+            ConvCall u = {dt, UP4, C, f.ch[l - 1], cur, pv(c, packed, c->up_w[l]), pf(c, packed, c->up_b[l]), nullptr, 0,
+                          nullptr, nullptr, XF_NONE, 0, tp.dn_y[l - 1].back(), tp.up_in[l - 1], w.stats, B, H, W};
+            CHK(run_conv(u, s, &np, &cs));
+        }
+    }
+    HIPCHK(conv_out_launch(dt, cur, tp.A, pf(c, packed, c->out_w), pf(c, packed, c->out_b), eps, B, f.ch[0], f.in_channels, T, f.f_size, s));
+    return 0;
+}
+
+// Backward of the whole network: d_eps [B][cio][T][F] fp32 -> every parameter gradient, WRITTEN into `grads`
+// (fp32, ddimx_grad_floats() floats; parameter i at ddimx_grad_offset(i) in its own shape; the temb.te buffer's slot is
+// left untouched).  x, t: the forward's inputs.  The gradient w.r.t. x is not produced (nothing upstream needs it).
+int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                   long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
+                   const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed, void* stream) {
+    if (!h || !packed || !packed_bwd || !tables || !workspace || !tape || !x || !t || !d_eps || !grads)
+        return fail("ddimx_unet_bwd: null argument");
+    const ddimx_ctx* c = h;
+    const ddimx_config& f = c->cfg;
+    const int L = c->L, dt = c->dtype;
+    if (B < 1 || T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("ddimx_unet_bwd: bad shape B=%d T=%d", B, T);
+    TrainWs w;
+    carve_train_ws(c, (char*)workspace, B, T, &w);
+    if ((long long)w.total > workspace_bytes) return fail("training workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
+    TrainTape tp;
+    carve_tape(c, (char*)const_cast<void*>(tape), B, T, &tp);
+    if ((long long)tp.total > tape_bytes) return fail("tape too small: need %zu bytes, got %lld", tp.total, tape_bytes);
+    BwdPack bp;
+    plan_bwd_pack(c, &bp);
+    const char* pb = (const char*)packed_bwd;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<long long> goff(c->specs.size());
+    {
+        long long n = 0;
+        for (size_t i = 0; i < c->specs.size(); ++i) { goff[i] = n; n += (c->specs[i].numel + 63) & ~63ll; }
+    }
+    auto G = [&](int i) { return grads + goff[i]; };
+    RBBwdWs rw = {w.du, w.dg, w.stats, w.coef, w.dgb, w.sums, w.partial};
+    auto rb_grads = [&](const RBW& r, float* dtemb) {
+        RBGrads g = {G(r.g0), G(r.b0), G(r.g1), G(r.b1), G(r.g2), G(r.w0), G(r.w1), G(r.bias1), dtemb, c->E};
+        return g;
+    };
+
+    // ---- output conv (models/diffusion.py:283-292): gradient of `x + hidden[0]`, weight / bias gradients
+    HIPCHK(conv_out_bwd_data_launch(dt, d_eps, pf(c, packed, c->out_w), w.gA, B, f.ch[0], f.in_channels, T, f.f_size, s));
+    HIPCHK(edge_wgrad_launch(dt, 1, tp.up_y[0].back(), tp.A, d_eps, w.partial, G(c->out_w), G(c->out_b), B, f.ch[0], f.in_channels, T,
+                             f.f_size, s));
+    // ---- up path, last level first executed = level 0 ... L-1
+    const void* gy = w.gA;
+    for (int l = 0; l < L; ++l) {
+        const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        for (int r = f.res[l] - 1; r >= 0; --r) {
+            const void* xin = r ? tp.up_y[l][r - 1] : tp.up_in[l];
+            void* dx = r == 0 ? w.GS[l] : (gy == w.Gb[l] ? w.Ga[l] : w.Gb[l]);
+            const RBW& rbw = c->up_rb[l][r];
+            CHK(run_resblock_bwd(dt, C, xin, tp.up_rb[l][r], gy, nullptr, dx, pf(c, packed, rbw.g0), pf(c, packed, rbw.g1),
+                                 pf(c, packed, rbw.g2), pb + bp.up_wd0[l][r], pb + bp.up_wd1[l][r],
+                                 rb_grads(rbw, w.dtemb + c->emb_off_up[up_bi(f, L, l, r)]), rw, B, H, W, s));
+            gy = dx;
+        }
+        // now GS[l] = d(up_in[l]) = gradient of the skip D_l as well
+        if (l < L - 1) {
+            const int Cn = f.ch[l + 1];
+            // up_in[l] = ConvTranspose2d(up_y[l+1].back()) + D_l
+            CHK(run_wgrad(dt, DOWN4, C, Cn, w.GS[l], tp.up_y[l + 1].back(), nullptr, nullptr, XF_NONE, w.partial, G(c->up_w[l + 1]), B,
+                          H / 2, W / 2, s));
+            CHK(channel_sums(dt, w.GS[l], w, G(c->up_b[l + 1]), B, H * W, C, s));
+            ConvCall d = {dt, DOWN4, C, Cn, w.GS[l], pb + bp.up_dg[l + 1], nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr,
+                          w.Ga[l + 1], nullptr, B, H, W};
+            CHK(run_conv(d, s, nullptr, nullptr));
+            gy = w.Ga[l + 1];
+        }
+    }
+    // ---- bottleneck: up_in[L-1] = D_{L-1} + O
+    const int S = T >> (L - 1), CL = f.ch[L - 1];
+    const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
+    const int bf = dt == DT_BF16;
+    const int C5 = CL, Fr = c->Fr;
+    const void* Dlast = tp.dn_y[L - 1].back();
+    HIPCHK(cast_f32_launch(dt, w.GS[L - 1], w.dO, (long long)M * width, s));
+    {   // compute_out: O = Xlast Wc^T + bc   (parameters live in the token-order permutation; gradients are un-permuted)
+        const float* Xlast = f.fnet_layers ? tp.fl[f.fnet_layers - 1].Xout : tp.X0;
+        HIPCHK(colsum_launch(w.dO, M, width, width, w.pgrad, s));
+        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->cout_b), 1, Fr, C5, s));
+        HIPCHK(transpose_launch(w.dO, w.T1, M, width, 0, s));
+        HIPCHK(transpose_launch(Xlast, w.T2, M, hid, 0, s));
+        CHK(tgemm(w, s, w.T1, w.T2, w.pgrad, width, hid, M, nullptr, nullptr, bf));
+        HIPCHK(pack_perm_rows_launch(w.pgrad, G(c->cout_w), Fr, C5, hid, s));
+        CHK(tgemm(w, s, w.dO, (const float*)(pb + bp.coutT), w.dXa, M, hid, width, nullptr, nullptr, bf));
+    }
+    for (int i = f.fnet_layers - 1; i >= 0; --i) {
+        const ddimx_ctx::FL& Lw = c->fl[i];
+        const TrainTape::FLT& q = tp.fl[i];
+        // output.LayerNorm(s), s = Y1 + dropout(FFN)
+        HIPCHK(ln_bwd_launch(DT_F32, w.dXa, q.s, nullptr, 1, q.sstat, pf(c, packed, Lw.ln2_w), w.dXb, w.lnpart, G(Lw.ln2_w), G(Lw.ln2_b),
+                             M, hid, s));
+        const float* dO2 = w.dXb;
+        if (dropout_p > 0.f) {
+            HIPCHK(dropout_apply_launch(w.dXb, w.dZ, (long long)M * hid, dropout_p, seed, (unsigned)(i + 1), s));
+            dO2 = w.dZ;
+        }
+        HIPCHK(colsum_launch(dO2, M, hid, hid, G(Lw.b2), s));
+        HIPCHK(transpose_launch(dO2, w.T1, M, hid, 0, s));
+        HIPCHK(transpose_launch(q.pre, w.T2, M, inter, 1, s));                                   // gelu(pre)^T
+        CHK(tgemm(w, s, w.T1, w.T2, G(Lw.w2), hid, inter, M, nullptr, nullptr, bf));             // dW2 [hid][inter]
+        CHK(tgemm(w, s, dO2, (const float*)(pb + bp.w2T[i]), w.dH, M, inter, hid, nullptr, nullptr, bf));
+        HIPCHK(gelu_launch(w.dH, q.pre, w.dH, (long long)M * inter, 1, s));                      // d(pre)
+        HIPCHK(colsum_launch(w.dH, M, inter, inter, G(Lw.b1), s));
+        HIPCHK(transpose_launch(w.dH, w.T1, M, inter, 0, s));
+        HIPCHK(transpose_launch(q.Y1, w.T2, M, hid, 0, s));
+        CHK(tgemm(w, s, w.T1, w.T2, G(Lw.w1), inter, hid, M, nullptr, nullptr, bf));             // dW1 [inter][hid]
+        CHK(tgemm(w, s, w.dH, (const float*)(pb + bp.w1T[i]), w.dXa, M, hid, inter, nullptr, w.dXb, bf));  // dY1 = ds + dpre W1
+        // fourier.output.LayerNorm(Z), Z = X + Re(FFT2(X))
+        HIPCHK(ln_bwd_launch(DT_F32, w.dXa, q.Z, nullptr, 1, q.zstat, pf(c, packed, Lw.ln1_w), w.dXb, w.lnpart, G(Lw.ln1_w), G(Lw.ln1_b),
+                             M, hid, s));
+        CHK(fourier_mix(c, tables, w, w.dXb, w.dXa, B, S, s));
+    }
+    {   // embedding: X0 = dropout(LN0(tok + posenc) Wp^T + bp)
+        if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(w.dXa, w.dXa, (long long)M * hid, dropout_p, seed, 0, s));
+        HIPCHK(colsum_launch(w.dXa, M, hid, hid, G(c->proj_b), s));
+        HIPCHK(transpose_launch(w.dXa, w.T1, M, hid, 0, s));
+        HIPCHK(transpose_launch(tp.ln0, w.T2, M, width, 0, s));
+        CHK(tgemm(w, s, w.T1, w.T2, w.pgrad, hid, width, M, nullptr, nullptr, bf));
+        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->proj_w), hid, Fr, C5, s));
+        CHK(tgemm(w, s, w.dXa, (const float*)(pb + bp.projT), w.dO, M, width, hid, nullptr, nullptr, bf));
+        HIPCHK(ln_bwd_launch(dt, w.dO, Dlast, tables->posenc, S, tp.ln0_stat, pf(c, packed, c->ln0_w), w.dTok, w.lnpart, w.pgrad,
+                             w.pgrad + width, M, width, s));
+        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->ln0_w), 1, Fr, C5, s));
+        HIPCHK(pack_perm_cols_launch(w.pgrad + width, G(c->ln0_b), 1, Fr, C5, s));
+    }
+    // d(D_{L-1}) = skip gradient + gradient through the bottleneck
+    HIPCHK(resid_launch(dt, w.GS[L - 1], w.dTok, 1, nullptr, nullptr, w.Ga[L - 1], nullptr, B, S * Fr, CL, s));
+    gy = w.Ga[L - 1];
+    // ---- down path
+    for (int l = L - 1; l >= 0; --l) {
+        const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        for (int r = f.res[l] - 1; r >= 0; --r) {
+            const void* xin = r ? tp.dn_y[l][r - 1] : tp.dn_in[l];
+            void* dx = gy == w.Gb[l] ? w.Ga[l] : w.Gb[l];
+            const RBW& rbw = c->down_rb[l][r];
+            CHK(run_resblock_bwd(dt, C, xin, tp.dn_rb[l][r], gy, (l == 0 && r == 0) ? w.gA : nullptr, dx, pf(c, packed, rbw.g0),
+                                 pf(c, packed, rbw.g1), pf(c, packed, rbw.g2), pb + bp.dn_wd0[l][r], pb + bp.dn_wd1[l][r],
+                                 rb_grads(rbw, w.dtemb + c->emb_off_down[down_bi(f, l, r)]), rw, B, H, W, s));
+            gy = dx;
+        }
+        if (l > 0) {
+            const int Cp = f.ch[l - 1];
+            // dn_in[l] = Conv2d(D_{l-1}, k4 s2 p1)
+            CHK(run_wgrad(dt, DOWN4, Cp, C, tp.dn_y[l - 1].back(), gy, nullptr, nullptr, XF_NONE, w.partial, G(c->down_w[l]), B, H, W, s));
+            CHK(channel_sums(dt, gy, w, G(c->down_b[l]), B, H * W, C, s));
+            ConvCall u = {dt, UP4, C, Cp, gy, pb + bp.down_dg[l], nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, w.GS[l - 1],
+                          w.Ga[l - 1], nullptr, B, H, W};
+            CHK(run_conv(u, s, nullptr, nullptr));
+            gy = w.Ga[l - 1];
+        }
+    }
+    // ---- input conv (models/diffusion.py:255-256): gy = d(hidden[0]) including the skip into the output conv
+    HIPCHK(edge_wgrad_launch(dt, 0, gy, nullptr, x, w.partial, G(c->in_w), G(c->in_b), B, f.ch[0], f.in_channels, T, f.f_size, s));
+    // ---- timestep-embedding MLP
+    HIPCHK(linear_bwd_w_launch(w.dtemb, tp.temb_h2p, nullptr, G(c->tw[2]), G(c->tb[2]), B, c->E, 512, 1, s));
+    HIPCHK(linear_bwd_x_launch(w.dtemb, pf(c, packed, c->tw[2]), tp.temb_h2p, w.dh2, B, c->E, 512, s));
+    HIPCHK(linear_bwd_w_launch(w.dh2, tp.temb_h1p, nullptr, G(c->tw[1]), G(c->tb[1]), B, 512, 512, 1, s));
+    HIPCHK(linear_bwd_x_launch(w.dh2, pf(c, packed, c->tw[1]), tp.temb_h1p, w.dh1, B, 512, 512, s));
+    HIPCHK(linear_bwd_w_launch(w.dh1, pf(c, packed, c->te), t, G(c->tw[0]), G(c->tb[0]), B, 512, 128, 0, s));
+    return 0;
+}
+
+int ddimx_sqerr_loss_bwd(const float* e, const float* out, const float* g_per_sample, float* d_out, int B, long long per_sample,
+                         void* stream) {
+    HIPCHK(sqerr_bwd_launch(e, out, g_per_sample, d_out, B, per_sample, (hipStream_t)stream));
+    return 0;
+}
+
 // ---- per-op entry points ---------------------------------------------------------------------------
 int ddimx_to_nhwc(int dtype, const float* nchw, void* nhwc, int B, int C, int H, int W, void* stream) {
     HIPCHK(to_nhwc_launch(dtype, nchw, nhwc, B, C, H * W, (hipStream_t)stream));

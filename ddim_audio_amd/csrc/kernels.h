@@ -33,8 +33,9 @@ hipError_t from_nhwc_launch(int dtype, const void* in, float* out, int B, int C,
 
 // ---- small dense layers (timestep embedding MLP, models/diffusion.py:110-120) ------------------------
 // y[b][n] = act(sum_k x[row(b)][k] * W[n][k] + bias[n]); row(b) = idx ? idx[b] : b
+// in_silu: SiLU is applied to x while it is read (training keeps the pre-activations)
 hipError_t linear_rows_launch(const float* x, const int64_t* idx, const float* W, const float* bias, float* y, int B,
-                              int N, int K, int act_silu, hipStream_t s);
+                              int N, int K, int act_silu, hipStream_t s, int in_silu = 0);
 
 // ---- LayerNorm over rows -----------------------------------------------------------------------------
 // y = LN(x [+ add[(m % add_rows)]]) * gamma + beta;  x is T (dtype) or fp32 (dtype = DT_F32)

@@ -525,7 +525,7 @@ hipError_t from_nhwc_launch(int dtype, const void* in, float* out, int B, int C,
 // =====================================================================================================
 __global__ void __launch_bounds__(256) linear_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
-                                                          float* __restrict__ y, int B, int N, int K, int act) {
+                                                          float* __restrict__ y, int B, int N, int K, int act, int in_silu) {
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const float* wr = W + (size_t)n * K;
@@ -539,7 +539,8 @@ __global__ void __launch_bounds__(256) linear_rows_kernel(const float* __restric
             for (int r = 0; r < 8; ++r) {
                 if (b0 + r < B) {
                     const size_t row = idx ? (size_t)idx[b0 + r] : (size_t)(b0 + r);
-                    const float4 xv = *(const float4*)(x + row * K + k);
+                    float4 xv = *(const float4*)(x + row * K + k);
+                    if (in_silu) { xv.x = silu_f(xv.x); xv.y = silu_f(xv.y); xv.z = silu_f(xv.z); xv.w = silu_f(xv.w); }
                     acc[r] = fmaf(xv.x, wv.x, acc[r]); acc[r] = fmaf(xv.y, wv.y, acc[r]);
                     acc[r] = fmaf(xv.z, wv.z, acc[r]); acc[r] = fmaf(xv.w, wv.w, acc[r]);
                 }
@@ -557,9 +558,9 @@ __global__ void __launch_bounds__(256) linear_rows_kernel(const float* __restric
 }
 
 hipError_t linear_rows_launch(const float* x, const int64_t* idx, const float* W, const float* bias, float* y, int B,
-                              int N, int K, int act_silu, hipStream_t s) {
+                              int N, int K, int act_silu, hipStream_t s, int in_silu) {
     if (K % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(linear_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, idx, W, bias, y, B, N, K, act_silu);
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, idx, W, bias, y, B, N, K, act_silu, in_silu);
     return hipGetLastError();
 }
 

@@ -18,8 +18,42 @@ hipError_t gn_bwd_apply_launch(int dtype, int mode, const void* g, const void* u
                                const float* coef, const float* scale, const float* shift, void* out, float* sums, int B,
                                int HW, int C, hipStream_t s);
 hipError_t colsum_launch(const float* src, int B, long long stride, int C, float* dst, hipStream_t s);
-hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s);
+// dst[b][c] = sum_p src[((b*nparts + p)*C + c) * src_step]   (src_step = 2 reads the `sum` half of (sum, sumsq) slabs)
+hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s,
+                          int src_step = 1);
 // data-gradient weights of a 3x3 conv: dst[tap'][ci][co] = w[co][ci][8 - tap'] in the activation dtype
 hipError_t pack_conv_dgrad_launch(int dtype, const float* w, void* dst, int O, int I, hipStream_t s);
+
+
+// ---- FNet bottleneck, training ---------------------------------------------------------------------------
+hipError_t dropout_apply_launch(const float* src, float* dst, long long n, float p, unsigned long long seed, unsigned stream,
+                                hipStream_t s);
+// y = LN(drop(x) + add[m % add_rows]); sum_out (nullable) keeps the pre-norm rows, stat [M][2] = (mean, rstd)
+hipError_t ln_train_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma, const float* beta,
+                           float eps, float* y, float* sum_out, float* stat, int M, int N, float p, unsigned long long seed,
+                           unsigned stream, hipStream_t s);
+int ln_bwd_nblocks(int M);
+// partial: ln_bwd_nblocks(M) * 2 * N floats
+hipError_t ln_bwd_launch(int x_dtype, const float* dy, const void* x, const float* add, int add_rows, const float* stat,
+                         const float* gamma, float* dx, float* partial, float* dgamma, float* dbeta, int M, int N, hipStream_t s);
+// mode 0: dst = gelu_new(src); mode 1: dst = src * gelu_new'(aux)
+hipError_t gelu_launch(const float* src, const float* aux, float* dst, long long n, int mode, hipStream_t s);
+hipError_t transpose_launch(const float* src, float* dst, int R, int C, int act_gelu, hipStream_t s);
+hipError_t cast_f32_launch(int dtype, const void* src, float* dst, long long n, hipStream_t s);
+
+// ---- timestep-embedding MLP backward -------------------------------------------------------------------------
+hipError_t linear_bwd_w_launch(const float* dy, const float* x, const int64_t* idx, float* dW, float* db, int B, int N, int K,
+                               int x_silu, hipStream_t s);
+hipError_t linear_bwd_x_launch(const float* dy, const float* W, const float* xpre, float* dx, int B, int N, int K, hipStream_t s);
+
+// ---- edge convolutions -----------------------------------------------------------------------------------------
+hipError_t conv_out_bwd_data_launch(int dtype, const float* d_eps, const float* w /*packed [9][cout][C0]*/, void* ds, int B, int C0,
+                                    int cout, int H, int W, hipStream_t s);
+size_t edge_wgrad_partial_floats(int B, int C, int NI, int H, int W);
+// mode 0: input conv (G = d hidden[0], S = x); mode 1: output conv (G = g1 + g2 = x + hidden[0], S = d_eps)
+hipError_t edge_wgrad_launch(int dtype, int mode, const void* g1, const void* g2, const float* S, float* partial, float* dW,
+                             float* db, int B, int C, int NI, int H, int W, hipStream_t s);
+// d_out[b] = 2 g[b] (out[b] - e[b]); g: upstream gradient of the per-sample losses [B]
+hipError_t sqerr_bwd_launch(const float* e, const float* out, const float* g, float* d, int B, long long per, hipStream_t s);
 
 }  // namespace ddimx

@@ -168,15 +168,16 @@ hipError_t colsum_launch(const float* src, int B, long long stride, int C, float
 }
 // dst[b][c] = sum_p src[b][p][c]
 __global__ void __launch_bounds__(256) partsum_kernel(const float* __restrict__ src, int nparts, int C, float* __restrict__ dst,
-                                                      long long dst_stride) {
+                                                      long long dst_stride, int src_step) {
     const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (c >= C) return;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)src[((size_t)b * nparts + p) * C + c];
+    for (int p = 0; p < nparts; ++p) s += (double)src[(((size_t)b * nparts + p) * C + c) * src_step];
     dst[(size_t)b * dst_stride + c] = (float)s;
 }
-hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s) {
-    hipLaunchKernelGGL(partsum_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, src, nparts, C, dst, dst_stride);
+hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s,
+                          int src_step) {
+    hipLaunchKernelGGL(partsum_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, src, nparts, C, dst, dst_stride, src_step);
     return hipGetLastError();
 }
 
@@ -291,6 +292,460 @@ hipError_t pack_conv_dgrad_launch(int dtype, const float* w, void* dst, int O, i
     const int blocks = (n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256;
     if (dtype == DT_BF16) hipLaunchKernelGGL(pack_conv_dgrad_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, w, (__bf16*)dst, O, I);
     else hipLaunchKernelGGL(pack_conv_dgrad_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)dst, O, I);
+    return hipGetLastError();
+}
+
+
+// =====================================================================================================
+// FNet bottleneck, training (models/diffusion.py:123-167 + transformers modeling_fnet.py:138-279)
+// =====================================================================================================
+// Dropout masks are a pure function of (seed, stream, element index) so the backward regenerates them instead of
+// storing them.  (The reference draws them from torch's global RNG; only the distribution can be matched.)
+__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned stream, unsigned long long e, unsigned thresh,
+                                              float inv_keep) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)stream + 1) + e * 0xD1342543DE82EF95ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) >= thresh ? inv_keep : 0.f;
+}
+static inline unsigned drop_thresh(float p) { return p <= 0.f ? 0u : (unsigned)((double)p * 4294967296.0); }
+
+__global__ void __launch_bounds__(256) dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n,
+                                                            unsigned long long seed, unsigned stream, unsigned thresh,
+                                                            float inv_keep) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+        dst[i] = src[i] * dropout_keep(seed, stream, (unsigned long long)i, thresh, inv_keep);
+}
+hipError_t dropout_apply_launch(const float* src, float* dst, long long n, float p, unsigned long long seed, unsigned stream,
+                                hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, seed, stream, drop_thresh(p),
+                       1.0f / (1.0f - p));
+    return hipGetLastError();
+}
+
+// y = LN(drop(x) + add[m % add_rows]) * gamma + beta; keeps the pre-norm row (sum_out, nullable) and (mean, rstd)
+template <typename TX>
+__global__ void __launch_bounds__(256) ln_train_kernel(const TX* __restrict__ x, const float* __restrict__ add, int add_rows,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float* __restrict__ y, float* __restrict__ sum_out,
+                                                       float* __restrict__ stat, int N, unsigned long long seed,
+                                                       unsigned stream, unsigned thresh, float inv_keep) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const TX* xr = x + (size_t)m * N;
+    const float* ar = add ? add + (size_t)(m % add_rows) * N : nullptr;
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        v[i] = 0.f;
+        if (n < N) {
+            float xv = to_f<TX>(xr[n]);
+            if (thresh) xv *= dropout_keep(seed, stream, (unsigned long long)m * N + n, thresh, inv_keep);
+            v[i] = xv + (ar ? ar[n] : 0.f);
+            s += v[i];
+            if (sum_out) sum_out[(size_t)m * N + n] = v[i];
+        }
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) bc = (red[0] + red[1] + red[2] + red[3]) / (float)N;
+    __syncthreads();
+    const float mean = bc;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        if (n < N) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    }
+    q = wave_sum(q);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) {
+        bc = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
+        stat[(size_t)m * 2 + 0] = mean;
+        stat[(size_t)m * 2 + 1] = bc;
+    }
+    __syncthreads();
+    const float rstd = bc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        if (n < N) y[(size_t)m * N + n] = (v[i] - mean) * rstd * gamma[n] + beta[n];
+    }
+}
+hipError_t ln_train_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma, const float* beta,
+                           float eps, float* y, float* sum_out, float* stat, int M, int N, float p, unsigned long long seed,
+                           unsigned stream, hipStream_t s) {
+    if (N > 2048) return hipErrorInvalidValue;
+    const unsigned th = drop_thresh(p);
+    const float ik = 1.0f / (1.0f - p);
+    if (x_dtype == DT_BF16)
+        hipLaunchKernelGGL(ln_train_kernel<__bf16>, dim3(M), dim3(256), 0, s, (const __bf16*)x, add, add_rows, gamma, beta, eps, y,
+                           sum_out, stat, N, seed, stream, th, ik);
+    else
+        hipLaunchKernelGGL(ln_train_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)x, add, add_rows, gamma, beta, eps, y,
+                           sum_out, stat, N, seed, stream, th, ik);
+    return hipGetLastError();
+}
+
+// LayerNorm backward.  x: the pre-norm rows (fp32 or, for the embedding norm, TX + add rows); stat: (mean, rstd).
+//   dx = rstd (gamma dy - mean_n(gamma dy) - xhat mean_n(gamma dy xhat)),  dgamma = sum_m dy xhat,  dbeta = sum_m dy
+// A block walks kLnRows rows and keeps the per-column parameter sums in registers: partial [nblocks][2][N].
+constexpr int kLnRows = 8;
+template <typename TX>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, const TX* __restrict__ x,
+                                                     const float* __restrict__ add, int add_rows, const float* __restrict__ stat,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx,
+                                                     float* __restrict__ partial, int M, int N) {
+    __shared__ float r1[4], r2[4];
+    __shared__ float b1, b2;
+    const int tid = threadIdx.x;
+    float gm[8], dgam[8], dbet[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        gm[i] = n < N ? gamma[n] : 0.f;
+        dgam[i] = dbet[i] = 0.f;
+    }
+    for (int rr = 0; rr < kLnRows; ++rr) {
+        const int m = blockIdx.x * kLnRows + rr;
+        if (m >= M) break;  // uniform
+        const float mean = stat[(size_t)m * 2], rstd = stat[(size_t)m * 2 + 1];
+        const float* ar = add ? add + (size_t)(m % add_rows) * N : nullptr;
+        float g[8], xh[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = tid + i * 256;
+            g[i] = xh[i] = 0.f;
+            if (n < N) {
+                const float d = dy[(size_t)m * N + n];
+                xh[i] = (to_f<TX>(x[(size_t)m * N + n]) + (ar ? ar[n] : 0.f) - mean) * rstd;
+                g[i] = d * gm[i];
+                s1 += g[i];
+                s2 = fmaf(g[i], xh[i], s2);
+                dgam[i] = fmaf(d, xh[i], dgam[i]);
+                dbet[i] += d;
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        __syncthreads();
+        if ((tid & 63) == 0) { r1[tid >> 6] = s1; r2[tid >> 6] = s2; }
+        __syncthreads();
+        if (tid == 0) { b1 = (r1[0] + r1[1] + r1[2] + r1[3]) / (float)N; b2 = (r2[0] + r2[1] + r2[2] + r2[3]) / (float)N; }
+        __syncthreads();
+        const float m1 = b1, m2 = b2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = tid + i * 256;
+            if (n < N) dx[(size_t)m * N + n] = rstd * (g[i] - m1 - xh[i] * m2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = tid + i * 256;
+        if (n < N) {
+            partial[((size_t)blockIdx.x * 2 + 0) * N + n] = dgam[i];
+            partial[((size_t)blockIdx.x * 2 + 1) * N + n] = dbet[i];
+        }
+    }
+}
+int ln_bwd_nblocks(int M) { return (M + kLnRows - 1) / kLnRows; }
+hipError_t ln_bwd_launch(int x_dtype, const float* dy, const void* x, const float* add, int add_rows, const float* stat,
+                         const float* gamma, float* dx, float* partial, float* dgamma, float* dbeta, int M, int N, hipStream_t s) {
+    if (N > 2048) return hipErrorInvalidValue;
+    const int nb = ln_bwd_nblocks(M);
+    if (x_dtype == DT_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<__bf16>, dim3(nb), dim3(256), 0, s, dy, (const __bf16*)x, add, add_rows, stat, gamma, dx, partial, M, N);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, dy, (const float*)x, add, add_rows, stat, gamma, dx, partial, M, N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, nb, 2ll * N, N, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial + N, nb, 2ll * N, N, dbeta);
+    return hipGetLastError();
+}
+
+// gelu_new and its derivative (transformers activations.py:59-66)
+__device__ __forceinline__ float dgelu_new_f(float v) {
+    const float k = 0.7978845608028654f, a = 0.044715f;
+    const float t = tanhf(k * (v + a * v * v * v));
+    return 0.5f * (1.0f + t) + 0.5f * v * (1.0f - t * t) * k * (1.0f + 3.0f * a * v * v);
+}
+// mode 0: dst = gelu_new(src);  mode 1: dst = src * gelu_new'(aux)
+__global__ void __launch_bounds__(256) gelu_kernel(const float* __restrict__ src, const float* __restrict__ aux,
+                                                   float* __restrict__ dst, long long n, int mode) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+        dst[i] = mode ? src[i] * dgelu_new_f(aux[i]) : gelu_new_f(src[i]);
+}
+hipError_t gelu_launch(const float* src, const float* aux, float* dst, long long n, int mode, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gelu_kernel, dim3(blocks), dim3(256), 0, s, src, aux, dst, n, mode);
+    return hipGetLastError();
+}
+
+// dst[c][r] = f(src[r][c]);  f = identity or gelu_new   (32x32 tiles through LDS)
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,
+                                                        int act) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) { v = src[(size_t)r * C + c]; if (act) v = gelu_new_f(v); }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < R && c < C) dst[(size_t)c * R + r] = tile[tx][j];
+    }
+}
+hipError_t transpose_launch(const float* src, float* dst, int R, int C, int act, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, dst, R, C, act);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) cast_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) dst[i] = to_f<T>(src[i]);
+}
+hipError_t cast_f32_launch(int dtype, const void* src, float* dst, long long n, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(cast_f32_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)src, dst, n);
+    else hipLaunchKernelGGL(cast_f32_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, dst, n);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// timestep-embedding MLP backward (models/diffusion.py:110-120): tiny dense layers, batch rows <= a few dozen
+// =====================================================================================================
+// dW[n][k] = sum_b dy[b][n] * f(x[row(b)][k]),  db[n] = sum_b dy[b][n];  f = SiLU when x_silu (x holds pre-activations)
+__global__ void __launch_bounds__(256) linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const int64_t* __restrict__ idx, float* __restrict__ dW,
+                                                           float* __restrict__ db, int B, int N, int K, int x_silu) {
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < K) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const size_t row = idx ? (size_t)idx[b] : (size_t)b;
+            float xv = x[row * K + k];
+            if (x_silu) xv = silu_f(xv);
+            acc = fmaf(dy[(size_t)b * N + n], xv, acc);
+        }
+        dW[(size_t)n * K + k] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += dy[(size_t)b * N + n];
+        db[n] = t;
+    }
+}
+// dx[b][k] = (sum_n dy[b][n] W[n][k]) * SiLU'(xpre[b][k])
+__global__ void __launch_bounds__(256) linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                           const float* __restrict__ xpre, float* __restrict__ dx, int N, int K) {
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc = fmaf(dy[(size_t)b * N + n], W[(size_t)n * K + k], acc);
+    dx[(size_t)b * K + k] = acc * dsilu_f(xpre[(size_t)b * K + k]);
+}
+hipError_t linear_bwd_w_launch(const float* dy, const float* x, const int64_t* idx, float* dW, float* db, int B, int N, int K,
+                               int x_silu, hipStream_t s) {
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((K + 255) / 256, N), dim3(256), 0, s, dy, x, idx, dW, db, B, N, K, x_silu);
+    return hipGetLastError();
+}
+hipError_t linear_bwd_x_launch(const float* dy, const float* W, const float* xpre, float* dx, int B, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((K + 255) / 256, B), dim3(256), 0, s, dy, W, xpre, dx, N, K);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// edge convolutions (models/diffusion.py:189-208): Conv2d(cio -> C0) at the input, Conv2d(C0 -> cio) at the output
+// =====================================================================================================
+// data gradient of the output conv: ds[b][y][x][c] = sum_{k,o} d_eps[b][o][y-ky+1][x-kx+1] * w[k][o][c]   (w: packed [9][cout][C0])
+// (d_eps NCHW fp32, ds NHWC T; it is the gradient of BOTH summands of `x + hidden[0]`, :284)
+template <typename T>
+__global__ void __launch_bounds__(256) conv_out_bwd_data_kernel(const float* __restrict__ de, const float* __restrict__ w,
+                                                                T* __restrict__ ds, int C0, int cout, int H, int W) {
+    constexpr int EPB = Piece<T>::N;
+    extern __shared__ float wl[];  // [k][o][c]: the forward's packed layout, copied as is
+    for (int i = threadIdx.x; i < 9 * cout * C0; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int CPP = C0 / EPB;
+    const long long pieces = (long long)H * W * CPP;
+    const int b = blockIdx.y;
+    for (long long pc = blockIdx.x * 256ll + threadIdx.x; pc < pieces; pc += gridDim.x * 256ll) {
+        const int c0 = (int)(pc % CPP) * EPB;
+        const long long pix = pc / CPP;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        float acc[EPB];
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) acc[j] = 0.f;
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y - k / 3 + 1, xx = x - k % 3 + 1;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            for (int o = 0; o < cout; ++o) {
+                const float d = de[(((size_t)b * cout + o) * H + yy) * W + xx];
+                const float* wp = wl + (k * cout + o) * C0 + c0;
+#pragma unroll
+                for (int j = 0; j < EPB; ++j) acc[j] = fmaf(d, wp[j], acc[j]);
+            }
+        }
+        *(uint4*)(ds + ((size_t)b * H * W + pix) * C0 + c0) = Piece<T>::pack(acc);
+    }
+}
+hipError_t conv_out_bwd_data_launch(int dtype, const float* d_eps, const float* w, void* ds, int B, int C0, int cout, int H,
+                                    int W, hipStream_t s) {
+    const int epb = dtype == DT_BF16 ? 8 : 4;
+    if (C0 % epb) return hipErrorInvalidValue;
+    const long long pieces = (long long)H * W * (C0 / epb);
+    dim3 grid((unsigned)((pieces + 255) / 256 < 4096 ? (pieces + 255) / 256 : 4096), B);
+    const size_t lds = (size_t)9 * cout * C0 * 4;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(conv_out_bwd_data_kernel<__bf16>, grid, dim3(256), lds, s, d_eps, w, (__bf16*)ds, C0, cout, H, W);
+    else
+        hipLaunchKernelGGL(conv_out_bwd_data_kernel<float>, grid, dim3(256), lds, s, d_eps, w, (float*)ds, C0, cout, H, W);
+    return hipGetLastError();
+}
+
+// weight gradients of both edge convs as one correlation:
+//   R[kk][i][c] = sum_{b,y,x} G[b][y][x][c] * S[b][i][y + ky - 1][x + kx - 1]     (zero padding of S)
+// G = g1 (+ g2): NHWC T with C channels; S: NCHW fp32 with NI <= 4 planes.
+//   input conv : G = d(hidden[0]), S = x       -> dW_in[c][i][kk]  = R[kk][i][c],     db_in[c]  = sumG[c]
+//   output conv: G = x + hidden[0], S = d_eps  -> dW_out[i][c][kk] = R[8 - kk][i][c], db_out[i] = sumS[i]
+// persistent blocks over 16x16 tiles; partial [nblocks][9*NI*C + C + NI]; edge_wgrad_reduce maps to the layouts.
+constexpr int kEdgeT = 16;
+template <typename T>
+__global__ void __launch_bounds__(288) edge_wgrad_kernel(const T* __restrict__ g1, const T* __restrict__ g2,
+                                                         const float* __restrict__ S, float* __restrict__ partial, int C, int NI,
+                                                         int H, int W, int tiles_x, int tiles_y, int total_tiles) {
+    extern __shared__ float sm[];
+    float* Gt = sm;                                   // [256][C + 1]
+    float* St = sm + 256 * (C + 1);                   // [NI][18][18]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int items = 9 * C;
+    float acc[2][4];  // up to 2 items per thread (items <= 2 * blockDim), NI <= 4
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[q][i] = 0.f;
+    float sumg = 0.f, sums = 0.f;
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y), tt = t % (tiles_x * tiles_y);
+        const int y0 = (tt / tiles_x) * kEdgeT, x0 = (tt % tiles_x) * kEdgeT;
+        __syncthreads();
+        for (int i = tid; i < 256 * C; i += nthr) {
+            const int c = i % C, p = i / C;
+            const int y = y0 + p / kEdgeT, x = x0 + p % kEdgeT;
+            float v = 0.f;
+            if (y < H && x < W) {
+                const size_t e = (((size_t)b * H + y) * W + x) * C + c;
+                v = to_f<T>(g1[e]);
+                if (g2) v += to_f<T>(g2[e]);
+            }
+            Gt[p * (C + 1) + c] = v;
+        }
+        for (int i = tid; i < NI * 18 * 18; i += nthr) {
+            const int xx = i % 18, yy = (i / 18) % 18, pl = i / 324;
+            const int y = y0 + yy - 1, x = x0 + xx - 1;
+            St[i] = (y >= 0 && y < H && x >= 0 && x < W) ? S[(((size_t)b * NI + pl) * H + y) * W + x] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int it = tid + q * nthr;
+            if (it >= items) break;
+            const int c = it % C, kk = it / C;
+            const int ky = kk / 3, kx = kk % 3;
+            for (int p = 0; p < 256; ++p) {
+                const float gv = Gt[p * (C + 1) + c];
+                const int so = (p / kEdgeT + ky) * 18 + p % kEdgeT + kx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < NI) acc[q][i] = fmaf(gv, St[i * 324 + so], acc[q][i]);
+            }
+        }
+        if (tid < C) {
+            for (int p = 0; p < 256; ++p) sumg += Gt[p * (C + 1) + tid];
+        } else if (tid - C < NI) {
+            const int pl = tid - C;
+            for (int p = 0; p < 256; ++p) sums += St[pl * 324 + (p / kEdgeT + 1) * 18 + p % kEdgeT + 1];
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * (9 * NI * C + C + NI);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int it = tid + q * nthr;
+        if (it >= items) break;
+        const int c = it % C, kk = it / C;
+        for (int i = 0; i < NI; ++i) out[(kk * NI + i) * C + c] = acc[q][i];
+    }
+    if (tid < C) out[9 * NI * C + tid] = sumg;
+    else if (tid - C < NI) out[9 * NI * C + C + tid - C] = sums;
+}
+// mode 0 (input conv): dW[c][i][kk], db[c] = sumG;  mode 1 (output conv): dW[i][c][kk] = R[8-kk], db[i] = sumS
+__global__ void __launch_bounds__(256) edge_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int C, int NI,
+                                                                int mode, float* __restrict__ dW, float* __restrict__ db) {
+    const int per = 9 * NI * C + C + NI;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    double s = 0.0;
+    for (int k = 0; k < nblocks; ++k) s += (double)partial[(size_t)k * per + i];
+    if (i < 9 * NI * C) {
+        const int c = i % C, pl = (i / C) % NI, kk = i / (C * NI);
+        if (mode == 0) dW[((size_t)c * NI + pl) * 9 + kk] = (float)s;
+        else dW[((size_t)pl * C + c) * 9 + (8 - kk)] = (float)s;
+    } else if (i < 9 * NI * C + C) {
+        if (mode == 0) db[i - 9 * NI * C] = (float)s;
+    } else if (mode == 1) {
+        db[i - 9 * NI * C - C] = (float)s;
+    }
+}
+int edge_wgrad_nblocks(int B, int H, int W) {
+    const long long t = (long long)B * ((H + kEdgeT - 1) / kEdgeT) * ((W + kEdgeT - 1) / kEdgeT);
+    return (int)(t < 1024 ? t : 1024);
+}
+size_t edge_wgrad_partial_floats(int B, int C, int NI, int H, int W) {
+    return (size_t)edge_wgrad_nblocks(B, H, W) * (9 * NI * C + C + NI);
+}
+hipError_t edge_wgrad_launch(int dtype, int mode, const void* g1, const void* g2, const float* S, float* partial, float* dW,
+                             float* db, int B, int C, int NI, int H, int W, hipStream_t s) {
+    if (NI > 4 || 9 * C > 2 * 288 || C + NI > 288) return hipErrorInvalidValue;
+    const int tx = (W + kEdgeT - 1) / kEdgeT, ty = (H + kEdgeT - 1) / kEdgeT;
+    const int nb = edge_wgrad_nblocks(B, H, W);
+    const size_t lds = (size_t)(256 * (C + 1) + NI * 324) * 4;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(edge_wgrad_kernel<__bf16>, dim3(nb), dim3(288), lds, s, (const __bf16*)g1, (const __bf16*)g2, S, partial,
+                           C, NI, H, W, tx, ty, B * tx * ty);
+    else
+        hipLaunchKernelGGL(edge_wgrad_kernel<float>, dim3(nb), dim3(288), lds, s, (const float*)g1, (const float*)g2, S, partial, C,
+                           NI, H, W, tx, ty, B * tx * ty);
+    const int per = 9 * NI * C + C + NI;
+    hipLaunchKernelGGL(edge_wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, s, partial, nb, C, NI, mode, dW, db);
+    return hipGetLastError();
+}
+
+// d(out)[b] = 2 * g[b] * (out[b] - e[b])   (functions/losses.py:18: per-sample sum of squares; g = upstream gradient per sample)
+__global__ void __launch_bounds__(256) sqerr_bwd_kernel(const float* __restrict__ e, const float* __restrict__ o,
+                                                        const float* __restrict__ g, float* __restrict__ d, long long per) {
+    const int b = blockIdx.y;
+    const float c = 2.0f * g[b];
+    const size_t base = (size_t)b * per;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < per; i += gridDim.x * 256ll) d[base + i] = c * (o[base + i] - e[base + i]);
+}
+hipError_t sqerr_bwd_launch(const float* e, const float* out, const float* g, float* d, int B, long long per, hipStream_t s) {
+    const int blocks = (int)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024);
+    hipLaunchKernelGGL(sqerr_bwd_kernel, dim3(blocks, B), dim3(256), 0, s, e, out, g, d, per);
     return hipGetLastError();
 }
 

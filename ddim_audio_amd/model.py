@@ -189,6 +189,60 @@ def _dft_tables(n):
     return np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
 
 
+class _UNetTrainFn(torch.autograd.Function):
+    """Autograd node of the training-mode forward: ddimx_unet_fwd_train keeps a tape, backward = ddimx_unet_bwd.
+    Gradients of all parameters land in ONE fresh fp32 buffer (views are handed to autograd), which is also the buffer a
+    data-parallel run all-reduces (``model.grad_sync``, see ddim_audio_amd/dist.py)."""
+
+    @staticmethod
+    def forward(ctx, model, x, t, tables, *params):
+        from . import _lib
+        import ctypes
+        lib = _lib.load()
+        b, t_len = x.size(0), x.size(2)
+        dev = x.device
+        need = int(lib.ddimx_train_workspace_bytes(model._handle, b, t_len))
+        ws = getattr(model, "_train_ws", None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            model._train_ws = None
+            ws = model._train_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        tape = torch.empty(int(lib.ddimx_train_tape_bytes(model._handle, b, t_len)), dtype=torch.uint8, device=dev)
+        out = torch.empty_like(x)
+        p = float(getattr(model.config.transformers.kwargs, "hidden_dropout_prob", 0.0))
+        model._dropout_calls = getattr(model, "_dropout_calls", 0) + 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + model._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        tb = _lib.DdimxTables(tables[0].data_ptr(), tables[1].data_ptr(), tables[2].data_ptr())
+        _lib.check(lib.ddimx_unet_fwd_train(model._handle, _lib.ptr(model._packed), ctypes.byref(tb), _lib.ptr(ws), ws.numel(),
+                                            _lib.ptr(tape), tape.numel(), _lib.ptr(x), _lib.ptr(t), _lib.ptr(out), b, t_len, p, seed,
+                                            _lib.stream()))
+        ctx.model, ctx.tape, ctx.x, ctx.t, ctx.tables, ctx.p, ctx.seed = model, tape, x, t, tables, p, seed
+        ctx.packed, ctx.packed_bwd = model._packed, model._packed_bwd  # keep the buffers this forward used alive
+        return out
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        from . import _lib
+        import ctypes
+        lib = _lib.load()
+        model, x = ctx.model, ctx.x
+        b, t_len = x.size(0), x.size(2)
+        total, layout = model._grad_layout(lib)
+        with torch.cuda.device(x.device):
+            flat = torch.empty(total, dtype=torch.float32, device=x.device)
+            ws = model._train_ws
+            tb = _lib.DdimxTables(ctx.tables[0].data_ptr(), ctx.tables[1].data_ptr(), ctx.tables[2].data_ptr())
+            g = d_eps.contiguous()
+            _lib.check(lib.ddimx_unet_bwd(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb), _lib.ptr(ws),
+                                          ws.numel(), _lib.ptr(ctx.tape), ctx.tape.numel(), _lib.ptr(x), _lib.ptr(ctx.t), _lib.ptr(g),
+                                          _lib.ptr(flat), b, t_len, ctx.p, ctx.seed, _lib.stream()))
+            sync = getattr(model, "grad_sync", None)
+            if sync is not None:
+                sync(flat)  # data parallel: average the whole gradient buffer over ranks (one RCCL all-reduce)
+        ctx.tape = None
+        model._last_flat_grad = flat
+        return (None, None, None, None) + tuple(flat[o:o + n].view(shape) for o, n, shape in layout)
+
+
 class Model(_Node):
     """Drop-in for reference ``models.diffusion.Model`` (``models/diffusion.py:170-294``)."""
 
@@ -299,6 +353,34 @@ class Model(_Node):
         self._packed_key = key
         self._dirty = False
 
+    def _ensure_packed_bwd(self, lib, device):
+        """Backward-only weight packings (data-gradient conv layouts, transposed FNet matrices); follows _ensure_packed."""
+        from . import _lib
+        if getattr(self, "_packed_bwd_key", None) == self._packed_key and getattr(self, "_packed_bwd", None) is not None:
+            return
+        tensors = self._state_tensors()
+        if getattr(self, "_packed_bwd", None) is None or self._packed_bwd.device != device:
+            self._packed_bwd = torch.empty(int(lib.ddimx_packed_bwd_bytes(self._handle)), dtype=torch.uint8, device=device)
+        import ctypes
+        arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        _lib.check(lib.ddimx_pack_weights_bwd(self._handle, arr, len(tensors), _lib.ptr(self._packed), _lib.ptr(self._packed_bwd),
+                                              _lib.stream()))
+        self._packed_bwd_key = self._packed_key
+
+    def _grad_layout(self, lib):
+        """(total floats, [(offset, numel, shape)] per parameter in named_parameters() order) of the flat gradient buffer."""
+        if getattr(self, "_glayout", None) is None:
+            offs = []
+            for i, (name, shape) in enumerate(self._inventory.items()):
+                if name == "temb.te":
+                    continue
+                numel = 1
+                for d in shape:
+                    numel *= d
+                offs.append((int(lib.ddimx_grad_offset(self._handle, i)), numel, tuple(shape)))
+            self._glayout = (int(lib.ddimx_grad_floats(self._handle)), offs)
+        return self._glayout
+
     def _ensure_tables(self, t_len, device):
         key = (t_len, str(device))
         if key not in self._tables:
@@ -323,9 +405,6 @@ class Model(_Node):
         if not input.is_cuda:
             raise RuntimeError("ddim_audio_amd.Model computes only through libddimx on a ROCm GPU; got a CPU tensor "
                                "(there is no CPU fallback)")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training-mode forward/backward kernels (dropout, autograd) are not built yet; "
-                                      "call model.eval() or run under torch.no_grad()")
         if input.dtype != torch.float32:
             raise RuntimeError("the network boundary is fp32 [B,C,T,F] (activations inside use config.model.dtype)")
         b, c, t_len, f = input.shape
@@ -344,6 +423,12 @@ class Model(_Node):
                 self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
             x = input.contiguous()
             tt = t.to(device=dev, dtype=torch.int64).contiguous()
+            if self.training and torch.is_grad_enabled():
+                # training step (reference runners/diffusion.py:134,143-150): tape-keeping forward, autograd node whose
+                # backward is ddimx_unet_bwd; dropout as in the reference's train mode (transformers hidden_dropout_prob)
+                self._ensure_packed_bwd(lib, dev)
+                params = [p for _, p in self.named_parameters()]
+                return _UNetTrainFn.apply(self, x, tt, (pe, dh, ds), *params)
             out = torch.empty_like(x)
             tables = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr())
             import ctypes

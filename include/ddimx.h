@@ -89,6 +89,38 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
                    long long workspace_bytes, const float* x, const int64_t* t, float* eps, int B, int T,
                    void* stream);
 
+/* ---- training: forward that keeps a tape + whole-network backward ------------------------------------
+ * The reference trains through autograd: functions/losses.py:12-18 builds the graph of Model.forward
+ * (models/diffusion.py:237-294, training mode: dropout hidden_dropout_prob after the FNet projection and after each FNet
+ * FFN) and runners/diffusion.py:150 `loss.backward()` walks it.  Here the forward stores, per Residual_Block, the two
+ * pre-activation conv outputs and the GroupNorm constants (plus the FNet rows) in `tape`, and ddimx_unet_bwd turns
+ * d_eps into all 388 parameter gradients.
+ *   packed_bwd : extra weight packings of the backward (data-gradient conv layouts, transposed FNet matrices), built by
+ *                ddimx_pack_weights_bwd from the same parameter tensors + the forward's packed buffer;
+ *   tape       : ddimx_train_tape_bytes(B, T) bytes, written by the forward, read by the backward;
+ *   workspace  : ddimx_train_workspace_bytes(B, T) bytes of scratch (shared by both calls);
+ *   grads      : fp32 [ddimx_grad_floats()], parameter i (plan order, as ddimx_param_info) at ddimx_grad_offset(i) in the
+ *                parameter's own shape; gradients are WRITTEN (not accumulated); the temb.te buffer's slot is untouched;
+ *   dropout    : masks are a pure function of (seed, layer, element), so the backward regenerates them: pass the same
+ *                (dropout_p, seed) to both calls.  dropout_p = 0 gives the deterministic function the parity tests use.
+ * The gradient w.r.t. the input x is not produced (the training step never needs it). */
+long long ddimx_packed_bwd_bytes(ddimx_handle h);
+int ddimx_pack_weights_bwd(ddimx_handle h, const void* const* params, int n_params, const void* packed, void* packed_bwd,
+                           void* stream);
+long long ddimx_train_tape_bytes(ddimx_handle h, int B, int T);
+long long ddimx_train_workspace_bytes(ddimx_handle h, int B, int T);
+long long ddimx_grad_floats(ddimx_handle h);
+long long ddimx_grad_offset(ddimx_handle h, int i);
+int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace,
+                         long long workspace_bytes, void* tape, long long tape_bytes, const float* x, const int64_t* t,
+                         float* eps, int B, int T, float dropout_p, unsigned long long seed, void* stream);
+int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                   long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
+                   const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed, void* stream);
+/* backward of the per-sample squared-error loss (functions/losses.py:18): d_out[b] = 2 g[b] (out[b] - e[b]) */
+int ddimx_sqerr_loss_bwd(const float* e, const float* out, const float* g_per_sample, float* d_out, int B,
+                         long long per_sample, void* stream);
+
 /* ---- per-op entry points (same kernels as ddimx_unet_fwd; used by the parity tests) ------------- */
 /* layout helpers: NCHW fp32 <-> NHWC activation dtype */
 int ddimx_to_nhwc(int dtype, const float* nchw, void* nhwc, int B, int C, int H, int W, void* stream);

@@ -34,3 +34,61 @@ def test_resblock_backward(dt, c, hw, b):
     G.check_close(dtemb, tr.grad, dt, f"dtemb C={c}", scale=4.0)
     for n, gv in grads.items():
         G.check_close(gv, leaf[p + n].grad, dt, f"d {n} C={c}", scale=4.0)
+
+
+# ---- whole network: loss.backward() through the reference-shaped Python API vs the reference's own gradients ----
+import ddim_audio_amd as D
+from ddim_audio_amd import configs, losses
+from ddim_audio_amd.schedule import make_schedule
+
+MODES = [("torch.cuda.FloatTensor", G.F32), ("torch.cuda.BFloat16Tensor", G.BF16)]
+
+
+def _train_model(name, dtype_str, seed, dropout=0.0):
+    d = configs.tiny_dict(dtype_str) if name == "tiny" else configs.audio_dict(dtype_str)
+    d["model"]["transformers"]["kwargs"]["hidden_dropout_prob"] = dropout
+    d["optimization"]["optimizer"]["default"]["optimizer"] = "Adam"
+    cfg = configs.dict2namespace(d)
+    m = D.Model(cfg)
+    synth.fill_module(m, seed)
+    return cfg, m.train()
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("name,shape,seed", [("tiny", (2, 2, 16, 32), 3), ("audio", (2, 2, 32, 256), 0)])
+def test_model_backward_golden(golden, mode, name, shape, seed):
+    """loss + all 388 parameter gradients against the digest the real reference produced (tests/golden/train.npz)."""
+    dtype_str, dt = mode
+    g = golden("train")
+    cfg, m = _train_model(name, dtype_str, seed)
+    _, alphas = make_schedule(cfg.diffusion)
+    x0, e = synth.gaussian(f"train.{name}.x0", shape).cuda(), synth.gaussian(f"train.{name}.e", shape).cuda()
+    t = torch.from_numpy(g[f"{name}_t"]).cuda()
+    loss = losses.noise_estimation_loss(m, x0, t, e, alphas.cuda())
+    loss.backward()
+    ref_loss = float(g[f"{name}_loss"])
+    assert abs(float(loss) - ref_loss) <= (1e-5 if dt == G.F32 else 2e-3) * ref_loss
+    names, norms = [str(n) for n in g[f"{name}_names"]], g[f"{name}_gnorms"]
+    total = float(np.sqrt((norms ** 2).sum()))
+    params = dict(m.named_parameters())
+    assert list(params.keys()) == names
+    worst = 0.0
+    got_total = 0.0
+    for pname, ref_norm in zip(names, norms):
+        grad = params[pname].grad
+        assert grad is not None and torch.isfinite(grad).all(), pname
+        flat = grad.detach().cpu().reshape(-1)
+        got_total += float(flat.double().square().sum())
+        ref = g[f"{name}_g::{pname}"]
+        stride = max(1, flat.numel() // 256)
+        got = flat[::stride][:256].numpy()
+        # per-tensor gate: relative to the tensor's own RMS gradient (floor: a 1e-4 share of the global norm)
+        rms_ref = ref_norm / np.sqrt(flat.numel())
+        scale = max(rms_ref, 1e-4 * total / np.sqrt(flat.numel()))
+        err = float(np.abs(got - ref).max()) / scale
+        worst = max(worst, err)
+        tol = 2e-3 if dt == G.F32 else 0.5
+        assert err <= tol, f"{pname}: max err {err:.3e} x rms (tol {tol})"
+        nerr = abs(float(flat.double().square().sum()) ** 0.5 - ref_norm) / max(ref_norm, 1e-4 * total)
+        assert nerr <= (5e-4 if dt == G.F32 else 6e-2), f"{pname}: norm err {nerr:.3e}"
+    assert abs(got_total ** 0.5 - total) <= (1e-4 if dt == G.F32 else 2e-2) * total
