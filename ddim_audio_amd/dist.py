@@ -1,6 +1,7 @@
 """Batch-parallel sampling across the GPUs of one node: one process per GPU, no collective in the
 step loop (every op of the path is per-sample: SURVEY section 8e), optional final all-gather over
-RCCL (``backend="nccl"`` on ROCm) or gloo."""
+RCCL (``backend="nccl"`` on ROCm) or gloo.  Training is data parallel: identical replicas, one all-reduce of the flat
+gradient buffer per step (``attach_grad_sync``)."""
 import torch
 import torch.distributed as dist
 
@@ -39,3 +40,29 @@ def sample_sharded(x_full, sampler, gather=True, group=None):
     n = x_full.size(0)
     local = sampler(shard_batch(x_full).clone())
     return gather_batch(local, n, group) if gather else local
+
+
+def make_grad_sync(group=None, bucket_mb=64):
+    """Data-parallel gradient averaging for the training step: the backward writes every parameter
+    gradient into ONE flat fp32 buffer (47.2 M elements = 188.6 MB for configs/audio.yml), which is all-reduced here in
+    ``bucket_mb`` slices issued back to back (RCCL pipelines them over the xGMI links) and scaled by 1/world.  The local
+    loss is a batch mean (functions/losses.py:18), so sum/world of the rank gradients is the global-batch gradient."""
+    def sync(flat):
+        if not dist.is_initialized():
+            return flat
+        world = dist.get_world_size(group)
+        if world == 1:
+            return flat
+        n = max(1, (bucket_mb << 20) // flat.element_size())
+        works = [dist.all_reduce(flat[i:i + n], op=dist.ReduceOp.SUM, group=group, async_op=True) for i in range(0, flat.numel(), n)]
+        for w in works:
+            w.wait()
+        flat.mul_(1.0 / world)
+        return flat
+    return sync
+
+
+def attach_grad_sync(model, group=None, bucket_mb=64):
+    """Make ``model``'s backward average its gradients over the ranks of ``group`` (one process per GPU)."""
+    model.grad_sync = make_grad_sync(group, bucket_mb)
+    return model

@@ -92,3 +92,88 @@ def test_model_backward_golden(golden, mode, name, shape, seed):
         nerr = abs(float(flat.double().square().sum()) ** 0.5 - ref_norm) / max(ref_norm, 1e-4 * total)
         assert nerr <= (5e-4 if dt == G.F32 else 6e-2), f"{pname}: norm err {nerr:.3e}"
     assert abs(got_total ** 0.5 - total) <= (1e-4 if dt == G.F32 else 2e-2) * total
+
+
+def test_training_steps_golden(golden):
+    """Two full optimisation steps (loss, backward, clip, fused Adam/AdamW, LambdaLR, EMA) against the reference's own
+    train_step tail (fp32 mode).  Adam divides by sqrt(v) + eps, which amplifies gradient noise where |g| ~ eps; the gate
+    is therefore on the parameter UPDATE relative to lr."""
+    from ddim_audio_amd import train
+    g = golden("train")
+    cfg, m = _train_model("tiny", "torch.cuda.FloatTensor", 3)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    state = train.TrainingState(cfg, m)
+    assert list(state.optimizers.keys()) == [str(s) for s in g["step_groups"]]
+    _, alphas = make_schedule(cfg.diffusion)
+    alphas = alphas.cuda()
+    shape = (2, 2, 16, 32)
+    for it in range(2):
+        sfx = f".{it}" if it else ""
+        x0, e = synth.gaussian(f"train.tiny.x0{sfx}", shape).cuda(), synth.gaussian(f"train.tiny.e{sfx}", shape).cuda()
+        t = torch.tensor([5, 994]) if it else torch.from_numpy(g["tiny_t"])
+        loss, norms = train.train_step(m, x0, state, alphas, e=e, t=t)
+        assert abs(float(loss) - float(g[f"step{it}_loss"])) < 1e-4 * float(g[f"step{it}_loss"])
+        for k, v in norms.items():
+            assert abs(float(v) - float(g[f"step{it}_norm_{k}"])) < 1e-3 * float(v)
+        bad = []
+        for n, p in m.named_parameters():
+            stride = max(1, p.numel() // 64)
+            got = p.detach().cpu().reshape(-1)[::stride][:64].numpy()
+            ref = g[f"step{it}_p::{n}"]
+            lr = 5e-4 if n.startswith("transformer.") else 3e-4
+            # updates are at most ~lr per step (times the warm-up factor); allow 2 % of lr per step taken
+            if np.abs(got - ref).max() > 0.02 * lr * (it + 1) + 1e-6 * np.abs(ref).max():
+                bad.append((n, float(np.abs(got - ref).max())))
+            sh = state.ema_helper.shadow[n].cpu().reshape(-1)[::stride][:64].numpy()
+            assert np.abs(sh - g[f"step{it}_ema::{n}"]).max() <= 1e-5 * np.abs(ref).max() + 1e-7, n
+        assert not bad, bad[:5]
+    assert np.allclose([o.param_groups[0]["lr"] for o in state.optimizers.values()], g["step_lrs"], rtol=1e-6)
+    moved = sum(int((p.detach() != before[n]).any()) for n, p in m.named_parameters())
+    assert moved == len(before)
+
+
+def test_dropout_training_mode():
+    """hidden_dropout_prob > 0 (the reference's train mode): masks are a function of (seed, call counter), the backward
+    regenerates them -- checked with a directional finite difference of the loss at a fixed mask (fp32 mode)."""
+    cfg, m = _train_model("tiny", "torch.cuda.FloatTensor", 3, dropout=0.1)
+    _, alphas = make_schedule(cfg.diffusion)
+    alphas = alphas.cuda()
+    shape = (2, 2, 16, 32)
+    x0, e = synth.gaussian("train.tiny.x0", shape).cuda(), synth.gaussian("train.tiny.e", shape).cuda()
+    t = torch.tensor([123, 876]).cuda()
+
+    def loss_at(call):
+        m._dropout_calls = call
+        return losses.noise_estimation_loss(m, x0, t, e, alphas)
+
+    l1 = loss_at(7)
+    l1.backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    l1b = loss_at(7)
+    l2 = loss_at(8)
+    assert float(l1) == float(l1b) and float(l1) != float(l2)       # same seed -> same mask; next call -> another mask
+    m.eval()
+    with torch.no_grad():
+        l_eval = losses.noise_estimation_loss(m, x0, t, e, alphas)
+    m.train()
+    assert abs(float(l1) - float(l_eval)) > 1e-6 * float(l_eval)     # dropout is really active in train mode
+    # directional derivative along a random direction restricted to the transformer (where dropout acts) + one conv
+    names = [n for n in g1 if n.startswith("transformer.")] + ["down_modules.1.0.conv.0.weight"]
+    params = dict(m.named_parameters())
+    dirs = {n: synth.gaussian("dd." + n, tuple(params[n].shape)).cuda() for n in names}
+    want = sum(float((g1[n].double() * dirs[n].double()).sum()) for n in names)
+    h = 1e-3
+    vals = []
+    for sgn in (+1, -1):
+        with torch.no_grad():
+            for n in names:
+                params[n].add_(dirs[n], alpha=sgn * h)
+        m.invalidate()
+        vals.append(float(loss_at(7).detach()))
+        with torch.no_grad():
+            for n in names:
+                params[n].add_(dirs[n], alpha=-sgn * h)
+    m.invalidate()
+    fd = (vals[0] - vals[1]) / (2 * h)
+    assert abs(fd - want) <= 2e-2 * abs(want) + 1e-3, (fd, want)

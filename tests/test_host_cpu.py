@@ -171,3 +171,54 @@ def test_product_package_never_touches_the_oracle_or_reference():
                 assert "/root/reference" not in src, os.path.join(root, f)
     bench = open(os.path.join(REPO, "bench.py")).read()
     assert bench.count("from oracle import") == 1 and "def cpu_baseline" in bench
+
+
+def _grad_sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)  # stand-in for the backward's flat gradient buffer
+        ddist.make_grad_sync(bucket_mb=1)(flat)                      # 1 MiB buckets -> several async all-reduces? (small: 1)
+        tiny = torch.arange(300001, dtype=torch.float32) + rank      # > 1 bucket at 1 MiB (262144 floats)
+        ddist.make_grad_sync(bucket_mb=1)(tiny)
+        want = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        want2 = torch.arange(300001, dtype=torch.float32) + (world - 1) / 2
+        q.put((rank, torch.allclose(flat, want), torch.allclose(tiny, want2)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_grad_sync_world2_gloo():
+    """The data-parallel collective of the training step: bucketed all-reduce + 1/world of the flat gradient buffer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(a and b for _, a, b in res)
+
+
+def test_classify_group_and_antithetic_timesteps():
+    """Parameter routing by top-level module name (runners/diffusion.py:71-87) and the antithetic draw (:141-142)."""
+    from ddim_audio_amd import train
+    from ddim_audio_amd.model import Model
+    cfg = configs.tiny_config("torch.FloatTensor")
+    m = Model(cfg)
+    groups = train.classify_group(cfg.optimization.optimizer, m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert set(groups) == {"transformer", "default"}
+    assert all(names[id(p)].startswith("transformer.") for p in groups["transformer"].params)
+    assert not any(names[id(p)].startswith("transformer.") for p in groups["default"].params)
+    assert len(groups["transformer"].params) + len(groups["default"].params) == len(names)
+    assert groups["default"].config.lr == 0.0003 and not hasattr(groups["default"].config, "top_level_name")
+    assert hasattr(cfg.optimization.optimizer.default, "top_level_name")  # the caller's config is left intact
+    clip = train.classify_group(cfg.optimization.grad_norm, m)
+    assert list(clip) == ["default"] and len(clip["default"].params) == len(names)
+    g = torch.Generator().manual_seed(5)
+    t = train.antithetic_timesteps(5, 1000, g)
+    assert t.shape == (5,) and int(t[0] + t[3]) == 999 and int(t[1] + t[4]) == 999
