@@ -19,20 +19,28 @@ hipError_t wgrad_launch(int dtype, int mode, int ci, int co, const WgradArgs& a,
     return dtype == DT_BF16 ? wgrad_launch_bf16(mode, ci, co, a, nsplit, s) : wgrad_launch_f32(mode, ci, co, a, nsplit, s);
 }
 
-// dst[co][ci][tap] = sum_s partial[s][tap][co][ci]
+// dst[co][ci][tap] = sum_s partial[s][tap][co][ci]; 4 threads share an output (splits s = q, q+4, ...), folded in a
+// fixed order through LDS
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int ntaps, int co,
                                                            int ci, float* __restrict__ dst) {
+    __shared__ double red[4][64];
     const int n = ntaps * co * ci;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int o64 = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o64;
     double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += (double)partial[(size_t)k * n + i];
-    const int c = i % ci, o = (i / ci) % co, tap = i / (ci * co);
-    dst[((size_t)o * ci + c) * ntaps + tap] = (float)s;
+    if (i < n)
+        for (int k = q; k < nsplit; k += 4) s += (double)partial[(size_t)k * n + i];
+    red[q][o64] = s;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        s = (red[0][o64] + red[1][o64]) + (red[2][o64] + red[3][o64]);
+        const int c = i % ci, o = (i / ci) % co, tap = i / (ci * co);
+        dst[((size_t)o * ci + c) * ntaps + tap] = (float)s;
+    }
 }
 hipError_t wgrad_reduce_launch(const float* partial, int nsplit, int ntaps, int co, int ci, float* dst, hipStream_t s) {
     const int n = ntaps * co * ci;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nsplit, ntaps, co, ci, dst);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partial, nsplit, ntaps, co, ci, dst);
     return hipGetLastError();
 }
 
@@ -118,66 +126,92 @@ hipError_t gn_bwd_stats_launch(int dtype, int mode, const void* g, const void* u
 //   ca = gamma_c rstd,  cb = -rstd^2 S2 / N,  cc = -rstd S1 / N + mean rstd^2 S2 / N
 // grid (groups, B)
 // =====================================================================================================
-__global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __restrict__ stats, int nparts, int C, double count,
-                                                             const float* __restrict__ gamma, const float* __restrict__ mr,
-                                                             float* __restrict__ coef /*[B][3][C]*/, float* __restrict__ dgb /*[B][2][C]*/) {
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ stats, int nparts, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mr,
+                                                              float* __restrict__ coef /*[B][3][C]*/, float* __restrict__ dgb /*[B][2][C]*/) {
+    __shared__ double rp[8][32], rq[8][32];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int GS = C / kGroups;
+    const int GS = C / kGroups;  // <= 32
     const float mean = mr[((size_t)b * kGroups + g) * 2 + 0], rstd = mr[((size_t)b * kGroups + g) * 2 + 1];
+    const int ch = tid & 31, pl = tid >> 5;  // 8 part-lanes per channel
+    const int c = g * GS + ch;
     double P = 0.0, Q = 0.0;
-    const int c = g * GS + tid;
-    if (tid < GS) {
-        for (int p = 0; p < nparts; ++p) {
+    if (ch < GS) {
+        for (int p = pl; p < nparts; p += 8) {
             const float* q = stats + (((size_t)b * nparts + p) * C + c) * 2;
             P += (double)q[0];
             Q += (double)q[1];
         }
     }
-    const double gm = tid < GS ? (double)gamma[c] : 0.0;
+    rp[pl][ch] = P; rq[pl][ch] = Q;
+    __syncthreads();
+    if (tid >= 64) return;
+    P = Q = 0.0;
+    if (tid < GS) {
+        for (int k = 0; k < 8; ++k) { P += rp[k][tid]; Q += rq[k][tid]; }
+    }
+    const int cc = g * GS + tid;
+    const double gm = tid < GS ? (double)gamma[cc] : 0.0;
     const double dg = (double)rstd * (Q - (double)mean * P);
     double s1 = gm * P, s2 = gm * dg;
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     if (tid < GS) {
         const double r = (double)rstd;
-        coef[((size_t)b * 3 + 0) * C + c] = (float)(gm * r);
-        coef[((size_t)b * 3 + 1) * C + c] = (float)(-r * r * s2 / count);
-        coef[((size_t)b * 3 + 2) * C + c] = (float)(-r * s1 / count + (double)mean * r * r * s2 / count);
-        dgb[((size_t)b * 2 + 0) * C + c] = (float)dg;
-        dgb[((size_t)b * 2 + 1) * C + c] = (float)P;
+        coef[((size_t)b * 3 + 0) * C + cc] = (float)(gm * r);
+        coef[((size_t)b * 3 + 1) * C + cc] = (float)(-r * r * s2 / count);
+        coef[((size_t)b * 3 + 2) * C + cc] = (float)(-r * s1 / count + (double)mean * r * r * s2 / count);
+        dgb[((size_t)b * 2 + 0) * C + cc] = (float)dg;
+        dgb[((size_t)b * 2 + 1) * C + cc] = (float)P;
     }
 }
 hipError_t gn_bwd_finalize_launch(const float* stats, int nparts, int C, double count, const float* gamma, const float* mr,
                                   float* coef, float* dgb, int B, hipStream_t s) {
-    if (C % kGroups || C / kGroups > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(kGroups, B), dim3(64), 0, s, stats, nparts, C, count, gamma, mr, coef, dgb);
+    if (C % kGroups || C / kGroups > 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(kGroups, B), dim3(256), 0, s, stats, nparts, C, count, gamma, mr, coef, dgb);
     return hipGetLastError();
 }
 
-// dst[c] = sum_b src[b * stride + c]   (fixed order)
+// dst[c] = sum_b src[b * stride + c]: 32 columns x 8 row-lanes per block, lanes folded in a fixed order
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ src, int B, long long stride, int C,
                                                      float* __restrict__ dst) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int b = 0; b < B; ++b) s += (double)src[(size_t)b * stride + c];
-    dst[c] = (float)s;
+    if (c < C)
+        for (int b = rl; b < B; b += 8) s += (double)src[(size_t)b * stride + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s = 0.0;
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        dst[c] = (float)s;
+    }
 }
 hipError_t colsum_launch(const float* src, int B, long long stride, int C, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, src, B, stride, C, dst);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 31) / 32), dim3(256), 0, s, src, B, stride, C, dst);
     return hipGetLastError();
 }
-// dst[b][c] = sum_p src[b][p][c]
+// dst[b][c] = sum_p src[((b*nparts + p)*C + c) * src_step]
 __global__ void __launch_bounds__(256) partsum_kernel(const float* __restrict__ src, int nparts, int C, float* __restrict__ dst,
                                                       long long dst_stride, int src_step) {
-    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, b = blockIdx.y;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)src[(((size_t)b * nparts + p) * C + c) * src_step];
-    dst[(size_t)b * dst_stride + c] = (float)s;
+    if (c < C)
+        for (int p = rl; p < nparts; p += 8) s += (double)src[(((size_t)b * nparts + p) * C + c) * src_step];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s = 0.0;
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        dst[(size_t)b * dst_stride + c] = (float)s;
+    }
 }
 hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s,
                           int src_step) {
-    hipLaunchKernelGGL(partsum_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, src, nparts, C, dst, dst_stride, src_step);
+    hipLaunchKernelGGL(partsum_kernel, dim3((C + 31) / 32, B), dim3(256), 0, s, src, nparts, C, dst, dst_stride, src_step);
     return hipGetLastError();
 }
 
@@ -467,8 +501,8 @@ hipError_t ln_bwd_launch(int x_dtype, const float* dy, const void* x, const floa
         hipLaunchKernelGGL(ln_bwd_kernel<__bf16>, dim3(nb), dim3(256), 0, s, dy, (const __bf16*)x, add, add_rows, stat, gamma, dx, partial, M, N);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, dy, (const float*)x, add, add_rows, stat, gamma, dx, partial, M, N);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, nb, 2ll * N, N, dgamma);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial + N, nb, 2ll * N, N, dbeta);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, s, partial, nb, 2ll * N, N, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, s, partial + N, nb, 2ll * N, N, dbeta);
     return hipGetLastError();
 }
 
@@ -549,14 +583,22 @@ __global__ void __launch_bounds__(256) linear_bwd_w_kernel(const float* __restri
         db[n] = t;
     }
 }
-// dx[b][k] = (sum_n dy[b][n] W[n][k]) * SiLU'(xpre[b][k])
+// dx[b][k] = (sum_n dy[b][n] W[n][k]) * SiLU'(xpre[b][k]); block = 16 k x 16 n-lanes
 __global__ void __launch_bounds__(256) linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W,
                                                            const float* __restrict__ xpre, float* __restrict__ dx, int N, int K) {
-    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ float red[16][17];
+    const int kl = threadIdx.x & 15, nl = threadIdx.x >> 4;
+    const int b = blockIdx.y, k = blockIdx.x * 16 + kl;
     float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc = fmaf(dy[(size_t)b * N + n], W[(size_t)n * K + k], acc);
-    dx[(size_t)b * K + k] = acc * dsilu_f(xpre[(size_t)b * K + k]);
+    if (k < K)
+        for (int n = nl; n < N; n += 16) acc = fmaf(dy[(size_t)b * N + n], W[(size_t)n * K + k], acc);
+    red[nl][kl] = acc;
+    __syncthreads();
+    if (nl == 0 && k < K) {
+        acc = 0.f;
+        for (int j = 0; j < 16; ++j) acc += red[j][kl];
+        dx[(size_t)b * K + k] = acc * dsilu_f(xpre[(size_t)b * K + k]);
+    }
 }
 hipError_t linear_bwd_w_launch(const float* dy, const float* x, const int64_t* idx, float* dW, float* db, int B, int N, int K,
                                int x_silu, hipStream_t s) {
@@ -564,7 +606,7 @@ hipError_t linear_bwd_w_launch(const float* dy, const float* x, const int64_t* i
     return hipGetLastError();
 }
 hipError_t linear_bwd_x_launch(const float* dy, const float* W, const float* xpre, float* dx, int B, int N, int K, hipStream_t s) {
-    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((K + 255) / 256, B), dim3(256), 0, s, dy, W, xpre, dx, N, K);
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((K + 15) / 16, B), dim3(256), 0, s, dy, W, xpre, dx, N, K);
     return hipGetLastError();
 }
 
@@ -692,14 +734,90 @@ __global__ void __launch_bounds__(288) edge_wgrad_kernel(const T* __restrict__ g
     if (tid < C) out[9 * NI * C + tid] = sumg;
     else if (tid - C < NI) out[9 * NI * C + C + tid - C] = sums;
 }
+// Fast path for the reference shape (C = 32 channels, NI <= 2 planes): no LDS in the loop.  A wave owns a strip of 8
+// columns x `rows` rows of one sample; lane = (channel lane & 31, plane lane >> 5).  The three S rows around the current
+// row live in registers (10 values each, one new row per step), G is read once per pixel: 72 FMAs per lane and row
+// against 18 small loads.  The block's four waves fold their 9 accumulators through LDS into one partial slab.
+constexpr int kStripW = 8;
+template <typename T>
+__global__ void __launch_bounds__(256) edge_wgrad_strip_kernel(const T* __restrict__ g1, const T* __restrict__ g2,
+                                                               const float* __restrict__ S, float* __restrict__ partial, int NI,
+                                                               int H, int W, int rows, int sx, int sy, int total_strips) {
+    constexpr int C = 32;
+    __shared__ float red[4][11][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, pl = lane >> 5;
+    const int strip = blockIdx.x * 4 + wave;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    float sumg = 0.f, sums = 0.f;
+    if (strip < total_strips && pl < NI) {
+        const int b = strip / (sx * sy), x0 = (strip % sx) * kStripW, y0 = ((strip / sx) % sy) * rows;
+        const int y1 = y0 + rows < H ? y0 + rows : H;
+        const float* Sp = S + ((size_t)b * NI + pl) * H * W;
+        float r0[10], r1[10], r2[10];
+        auto load_row = [&](int y, float (&r)[10]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int x = x0 - 1 + j;
+                r[j] = (y >= 0 && y < H && x >= 0 && x < W) ? Sp[(size_t)y * W + x] : 0.f;
+            }
+        };
+        load_row(y0 - 1, r0);
+        load_row(y0, r1);
+        for (int y = y0; y < y1; ++y) {
+            load_row(y + 1, r2);
+            const size_t rowe = (((size_t)b * H + y) * W + x0) * C + c;
+#pragma unroll
+            for (int px = 0; px < kStripW; ++px) {
+                float gv = 0.f;
+                if (x0 + px < W) {
+                    gv = to_f<T>(g1[rowe + (size_t)px * C]);
+                    if (g2) gv += to_f<T>(g2[rowe + (size_t)px * C]);
+                    sums += r1[px + 1];
+                }
+                sumg += gv;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    acc[kx] = fmaf(gv, r0[px + kx], acc[kx]);
+                    acc[3 + kx] = fmaf(gv, r1[px + kx], acc[3 + kx]);
+                    acc[6 + kx] = fmaf(gv, r2[px + kx], acc[6 + kx]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[wave][k][lane] = acc[k];
+    red[wave][9][lane] = sumg;
+    red[wave][10][lane] = sums;
+    __syncthreads();
+    if (wave == 0 && pl < NI) {
+        float* out = partial + (size_t)blockIdx.x * (9 * NI * C + C + NI);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            out[(k * NI + pl) * C + c] = (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
+        if (pl == 0) out[9 * NI * C + c] = (red[0][9][lane] + red[1][9][lane]) + (red[2][9][lane] + red[3][9][lane]);
+        if (c == 0) out[9 * NI * C + C + pl] = (red[0][10][lane] + red[1][10][lane]) + (red[2][10][lane] + red[3][10][lane]);
+    }
+}
+
 // mode 0 (input conv): dW[c][i][kk], db[c] = sumG;  mode 1 (output conv): dW[i][c][kk] = R[8-kk], db[i] = sumS
 __global__ void __launch_bounds__(256) edge_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int C, int NI,
                                                                 int mode, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ double red[4][64];
     const int per = 9 * NI * C + C + NI;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= per) return;
+    const int o64 = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o64;
     double s = 0.0;
-    for (int k = 0; k < nblocks; ++k) s += (double)partial[(size_t)k * per + i];
+    if (i < per)
+        for (int k = q; k < nblocks; k += 4) s += (double)partial[(size_t)k * per + i];
+    red[q][o64] = s;
+    __syncthreads();
+    if (q != 0 || i >= per) return;
+    s = (red[0][o64] + red[1][o64]) + (red[2][o64] + red[3][o64]);
     if (i < 9 * NI * C) {
         const int c = i % C, pl = (i / C) % NI, kk = i / (C * NI);
         if (mode == 0) dW[((size_t)c * NI + pl) * 9 + kk] = (float)s;
@@ -710,28 +828,44 @@ __global__ void __launch_bounds__(256) edge_wgrad_reduce_kernel(const float* __r
         db[i - 9 * NI * C - C] = (float)s;
     }
 }
-int edge_wgrad_nblocks(int B, int H, int W) {
+constexpr int kStripRows = 128;
+static inline bool edge_fast(int C, int NI) { return C == 32 && NI <= 2; }
+int edge_wgrad_nblocks(int B, int C, int NI, int H, int W) {
+    if (edge_fast(C, NI)) {
+        const long long strips = (long long)B * ((W + kStripW - 1) / kStripW) * ((H + kStripRows - 1) / kStripRows);
+        return (int)((strips + 3) / 4);
+    }
     const long long t = (long long)B * ((H + kEdgeT - 1) / kEdgeT) * ((W + kEdgeT - 1) / kEdgeT);
     return (int)(t < 1024 ? t : 1024);
 }
 size_t edge_wgrad_partial_floats(int B, int C, int NI, int H, int W) {
-    return (size_t)edge_wgrad_nblocks(B, H, W) * (9 * NI * C + C + NI);
+    return (size_t)edge_wgrad_nblocks(B, C, NI, H, W) * (9 * NI * C + C + NI);
 }
 hipError_t edge_wgrad_launch(int dtype, int mode, const void* g1, const void* g2, const float* S, float* partial, float* dW,
                              float* db, int B, int C, int NI, int H, int W, hipStream_t s) {
     if (NI > 4 || 9 * C > 2 * 288 || C + NI > 288) return hipErrorInvalidValue;
-    const int tx = (W + kEdgeT - 1) / kEdgeT, ty = (H + kEdgeT - 1) / kEdgeT;
-    const int nb = edge_wgrad_nblocks(B, H, W);
-    const size_t lds = (size_t)(256 * (C + 1) + NI * 324) * 4;
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    if (dtype == DT_BF16)
-        hipLaunchKernelGGL(edge_wgrad_kernel<__bf16>, dim3(nb), dim3(288), lds, s, (const __bf16*)g1, (const __bf16*)g2, S, partial,
-                           C, NI, H, W, tx, ty, B * tx * ty);
-    else
-        hipLaunchKernelGGL(edge_wgrad_kernel<float>, dim3(nb), dim3(288), lds, s, (const float*)g1, (const float*)g2, S, partial, C,
-                           NI, H, W, tx, ty, B * tx * ty);
+    const int nb = edge_wgrad_nblocks(B, C, NI, H, W);
+    if (edge_fast(C, NI)) {
+        const int sx = (W + kStripW - 1) / kStripW, sy = (H + kStripRows - 1) / kStripRows;
+        if (dtype == DT_BF16)
+            hipLaunchKernelGGL(edge_wgrad_strip_kernel<__bf16>, dim3(nb), dim3(256), 0, s, (const __bf16*)g1, (const __bf16*)g2, S, partial,
+                               NI, H, W, kStripRows, sx, sy, B * sx * sy);
+        else
+            hipLaunchKernelGGL(edge_wgrad_strip_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)g1, (const float*)g2, S, partial,
+                               NI, H, W, kStripRows, sx, sy, B * sx * sy);
+    } else {
+        const int tx = (W + kEdgeT - 1) / kEdgeT, ty = (H + kEdgeT - 1) / kEdgeT;
+        const size_t lds = (size_t)(256 * (C + 1) + NI * 324) * 4;
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        if (dtype == DT_BF16)
+            hipLaunchKernelGGL(edge_wgrad_kernel<__bf16>, dim3(nb), dim3(288), lds, s, (const __bf16*)g1, (const __bf16*)g2, S, partial,
+                               C, NI, H, W, tx, ty, B * tx * ty);
+        else
+            hipLaunchKernelGGL(edge_wgrad_kernel<float>, dim3(nb), dim3(288), lds, s, (const float*)g1, (const float*)g2, S, partial, C,
+                               NI, H, W, tx, ty, B * tx * ty);
+    }
     const int per = 9 * NI * C + C + NI;
-    hipLaunchKernelGGL(edge_wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, s, partial, nb, C, NI, mode, dW, db);
+    hipLaunchKernelGGL(edge_wgrad_reduce_kernel, dim3((per + 63) / 64), dim3(256), 0, s, partial, nb, C, NI, mode, dW, db);
     return hipGetLastError();
 }
 

@@ -216,6 +216,7 @@ class _UNetTrainFn(torch.autograd.Function):
                                             _lib.ptr(tape), tape.numel(), _lib.ptr(x), _lib.ptr(t), _lib.ptr(out), b, t_len, p, seed,
                                             _lib.stream()))
         ctx.model, ctx.tape, ctx.x, ctx.t, ctx.tables, ctx.p, ctx.seed = model, tape, x, t, tables, p, seed
+        ctx.params = params
         ctx.packed, ctx.packed_bwd = model._packed, model._packed_bwd  # keep the buffers this forward used alive
         return out
 
@@ -228,7 +229,14 @@ class _UNetTrainFn(torch.autograd.Function):
         b, t_len = x.size(0), x.size(2)
         total, layout = model._grad_layout(lib)
         with torch.cuda.device(x.device):
-            flat = torch.empty(total, dtype=torch.float32, device=x.device)
+            # One flat gradient buffer, kept across steps while no parameter holds a gradient (the usual
+            # zero_grad(set_to_none=True) loop): the .grad tensors are views of it, like DDP's gradient_as_bucket_view,
+            # so the fused optimizer's pointer tables stay valid.  If gradients are being accumulated a fresh buffer is used.
+            flat = getattr(model, "_flat_grad", None)
+            if flat is None or flat.numel() != total or flat.device != x.device or any(q.grad is not None for q in ctx.params):
+                flat = torch.empty(total, dtype=torch.float32, device=x.device)
+                if all(q.grad is None for q in ctx.params):
+                    model._flat_grad = flat
             ws = model._train_ws
             tb = _lib.DdimxTables(ctx.tables[0].data_ptr(), ctx.tables[1].data_ptr(), ctx.tables[2].data_ptr())
             g = d_eps.contiguous()
@@ -239,7 +247,6 @@ class _UNetTrainFn(torch.autograd.Function):
             if sync is not None:
                 sync(flat)  # data parallel: average the whole gradient buffer over ranks (one RCCL all-reduce)
         ctx.tape = None
-        model._last_flat_grad = flat
         return (None, None, None, None) + tuple(flat[o:o + n].view(shape) for o, n, shape in layout)
 
 
