@@ -632,11 +632,14 @@ __global__ void __launch_bounds__(256) conv_out_bwd_data_kernel(const float* __r
         float acc[EPB];
 #pragma unroll
         for (int j = 0; j < EPB; ++j) acc[j] = 0.f;
+#pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int yy = y - k / 3 + 1, xx = x - k % 3 + 1;
-            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t off = ok ? (size_t)yy * W + xx : 0;
             for (int o = 0; o < cout; ++o) {
-                const float d = de[(((size_t)b * cout + o) * H + yy) * W + xx];
+                const float dv = de[((size_t)b * cout + o) * H * W + off];
+                const float d = ok ? dv : 0.f;
                 const float* wp = wl + (k * cout + o) * C0 + c0;
 #pragma unroll
                 for (int j = 0; j < EPB; ++j) acc[j] = fmaf(d, wp[j], acc[j]);
@@ -757,27 +760,46 @@ __global__ void __launch_bounds__(256) edge_wgrad_strip_kernel(const T* __restri
         const int y1 = y0 + rows < H ? y0 + rows : H;
         const float* Sp = S + ((size_t)b * NI + pl) * H * W;
         float r0[10], r1[10], r2[10];
+        // unconditional loads at clamped coordinates, zeroed by select afterwards: all loads of a row issue back to back
         auto load_row = [&](int y, float (&r)[10]) __attribute__((always_inline)) {
+            const bool yok = y >= 0 && y < H;
+            const float* rowp = Sp + (size_t)(yok ? y : 0) * W;
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
                 const int x = x0 - 1 + j;
-                r[j] = (y >= 0 && y < H && x >= 0 && x < W) ? Sp[(size_t)y * W + x] : 0.f;
+                const bool ok = yok && x >= 0 && x < W;
+                const float v = rowp[ok ? x : 0];
+                r[j] = ok ? v : 0.f;
             }
         };
-        load_row(y0 - 1, r0);
-        load_row(y0, r1);
-        for (int y = y0; y < y1; ++y) {
-            load_row(y + 1, r2);
-            const size_t rowe = (((size_t)b * H + y) * W + x0) * C + c;
+        // G row (8 pixels of this lane's channel); loads are unconditional at clamped coordinates
+        auto load_g = [&](int y, float (&gr)[kStripW]) __attribute__((always_inline)) {
+            const bool yok = y < y1;
+            const size_t rowe = (((size_t)b * H + (yok ? y : y0)) * W + x0) * C + c;
 #pragma unroll
             for (int px = 0; px < kStripW; ++px) {
-                float gv = 0.f;
-                if (x0 + px < W) {
-                    gv = to_f<T>(g1[rowe + (size_t)px * C]);
-                    if (g2) gv += to_f<T>(g2[rowe + (size_t)px * C]);
-                    sums += r1[px + 1];
-                }
+                const bool ok = yok && x0 + px < W;
+                const size_t e = ok ? rowe + (size_t)px * C : rowe;
+                float v = to_f<T>(g1[e]);
+                if (g2) v += to_f<T>(g2[e]);
+                gr[px] = ok ? v : 0.f;
+            }
+        };
+        float gc[kStripW], gn[kStripW], r3[10];
+        load_row(y0 - 1, r0);
+        load_row(y0, r1);
+        load_row(y0 + 1, r2);
+        load_g(y0, gc);
+#pragma unroll 1
+        for (int y = y0; y < y1; ++y) {
+            // the next row's operands are requested before this row's arithmetic (one row in flight per wave)
+            load_row(y + 2, r3);
+            load_g(y + 1, gn);
+#pragma unroll
+            for (int px = 0; px < kStripW; ++px) {
+                const float gv = gc[px];
                 sumg += gv;
+                sums += (x0 + px < W) ? r1[px + 1] : 0.f;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     acc[kx] = fmaf(gv, r0[px + kx], acc[kx]);
@@ -786,7 +808,9 @@ __global__ void __launch_bounds__(256) edge_wgrad_strip_kernel(const T* __restri
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 10; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            for (int j = 0; j < 10; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; r2[j] = r3[j]; }
+#pragma unroll
+            for (int px = 0; px < kStripW; ++px) gc[px] = gn[px];
         }
     }
 #pragma unroll
