@@ -830,6 +830,7 @@ hipError_t grad_norm_multi_launch(const long long* ptrs, const long long* sizes,
     return hipGetLastError();
 }
 
+// decoupled = 2: AdaBelief (Zhuang et al. 2020, weight_decouple, no rectification, no amsgrad): v <- b2 v + (1-b2)(g-m)^2 + eps.
 // g *= coef[1] (the clip coefficient stays on the device: no host sync), then Adam / AdamW (torch semantics,
 // amsgrad off): decoupled: p *= 1 - lr*wd ; else g += wd*p.  m = m + (1-b1)(g - m); v = b2*v + (1-b2) g*g;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t) from the host.
@@ -850,7 +851,13 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamArgs a) {
         if (a.decoupled) pk = __fmul_rn(pk, 1.0f - a.lr * a.wd);
         else gk = fmaf(a.wd, pk, gk);
         const float mk = fmaf(1.0f - a.b1, __fsub_rn(gk, m[k]), m[k]);
-        const float vk = fmaf(__fmul_rn(gk, gk), 1.0f - a.b2, __fmul_rn(v[k], a.b2));
+        float vk;
+        if (a.decoupled == 2) {  // AdaBelief: the second moment follows (g - m)^2 and absorbs eps every step
+            const float r = __fsub_rn(gk, mk);
+            vk = __fadd_rn(fmaf(__fmul_rn(r, r), 1.0f - a.b2, __fmul_rn(v[k], a.b2)), a.eps);
+        } else {
+            vk = fmaf(__fmul_rn(gk, gk), 1.0f - a.b2, __fmul_rn(v[k], a.b2));
+        }
         const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vk), a.bc2s), a.eps);
         pk = fmaf(-step_size, __fdiv_rn(mk, denom), pk);
         g[k] = gk; m[k] = mk; v[k] = vk; p[k] = pk;

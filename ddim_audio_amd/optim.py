@@ -3,9 +3,11 @@
 ``get_optimizer`` returns fused multi-tensor optimizers for ``Adam`` / ``AdamW`` (one libddimx launch per group
 instead of ~10 tiny launches per tensor); ``clip_grad_norm_`` is the fused counterpart of
 ``torch.nn.utils.clip_grad_norm_`` (global L2 norm + in-place scaling, the coefficient never leaves the device).
-``AdaBelief`` lives in an un-vendored submodule of the reference (``External/step-clip-optimizer``): its source is
-absent, so it is not reproduced here (parity would be unpinned) -- requesting it raises.  RMSProp / SGD pass through
-to ``torch.optim``.  CPU tensors are rejected: like the rest of the package there is no CPU fallback.
+``AdaBelief`` lives in an un-vendored submodule of the reference (``External/step-clip-optimizer``, source absent):
+it is implemented from the published algorithm (Zhuang et al. 2020) with the flags the reference passes
+(``weight_decouple=True, fixed_decay=False, rectify=False``); ``clip_step`` other than ``None`` raises.  PARITY UNPINNED
+for this optimizer: it is checked against a restatement of the paper's update only.  RMSProp / SGD pass through to
+``torch.optim``.  CPU tensors are rejected: like the rest of the package there is no CPU fallback.
 """
 import torch
 import torch.optim as optim
@@ -74,6 +76,7 @@ class FusedAdam(optim.Optimizer):
     multi-tensor HIP launch per parameter group.  ``param_groups[i]['lr']`` is honoured, so ``LambdaLR`` works."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, decoupled=True):
+        """decoupled: False = Adam (L2 in the gradient), True = AdamW, 2 = AdaBelief (decoupled decay)."""
         if amsgrad:
             raise NotImplementedError("amsgrad is not implemented in the fused optimizer")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, decoupled=decoupled))
@@ -111,7 +114,7 @@ class FusedAdam(optim.Optimizer):
                 _lib.check(lib.ddimx_adam_multi(_lib.ptr(tb.ptrs[0]), _lib.ptr(tb.ptrs[1]), _lib.ptr(tb.ptrs[2]), _lib.ptr(tb.ptrs[3]),
                                                 _lib.ptr(tb.sizes), _lib.ptr(tb.bt), _lib.ptr(tb.bo), tb.nblk, None, float(group["lr"]),
                                                 float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                                int(steps.pop()), 1 if group["decoupled"] else 0, _lib.stream()))
+                                                int(steps.pop()), int(group["decoupled"]), _lib.stream()))
         return loss
 
 
@@ -120,8 +123,11 @@ def get_optimizer(config, parameters):
         return FusedAdam(parameters, lr=config.lr, weight_decay=config.weight_decay, betas=config.beta, amsgrad=config.amsgrad,
                          eps=config.eps, decoupled=config.optimizer == "AdamW")
     if config.optimizer == "AdaBelief":
-        raise NotImplementedError("AdaBelief comes from the reference's un-vendored step-clip-optimizer submodule (source "
-                                  "absent): use AdamW for this group")
+        if getattr(config, "clip_step", None) is not None:
+            raise NotImplementedError("AdaBelief clip_step belongs to the reference's un-vendored step-clip-optimizer fork "
+                                      "(source absent); only clip_step: null is implemented")
+        return FusedAdam(parameters, lr=config.lr, weight_decay=config.weight_decay, betas=config.beta, amsgrad=config.amsgrad,
+                         eps=config.eps, decoupled=2)
     if config.optimizer == "RMSProp":
         return optim.RMSprop(parameters, lr=config.lr, weight_decay=config.weight_decay)
     if config.optimizer == "SGD":

@@ -216,7 +216,9 @@ int ddimx_ema_update_multi(const long long* shadow_ptrs, const long long* param_
  * Multi-tensor launches over device pointer tables (block tables as for ddimx_ema_update_multi).
  * grad_norm: out[0] = global L2 norm of all gradients, out[1] = min(1, max_norm/(norm+1e-6)) -- the coefficient of
  * torch.nn.utils.clip_grad_norm_ -- kept on the device (no host sync); partial: [nblocks] scratch.
- * adam: g *= clip[1] (if clip != null), then torch.optim.Adam (decoupled = 0) / AdamW (decoupled = 1), amsgrad off. */
+ * adam: g *= clip[1] (if clip != null), then torch.optim.Adam (decoupled = 0) / AdamW (decoupled = 1), amsgrad off;
+ * decoupled = 2: AdaBelief as published (Zhuang et al. 2020; decoupled decay, no rectification) -- the reference's default
+ * optimizer (functions/__init__.py:24-42) comes from an un-vendored submodule, so this mode has no reference pin. */
 int ddimx_grad_norm_multi(const long long* grad_ptrs, const long long* sizes, const int* blk_tensor,
                           const long long* blk_off, int nblocks, float max_norm, float* partial, float* out, void* stream);
 /* every tensor *= coef[0] (device scalar): the in-place scaling of clip_grad_norm_ */

@@ -278,3 +278,17 @@ def train_step(st, x0, e, t, alphas, mu=0.9999):
     with torch.no_grad():
         st.shadow = ema_update(st.shadow, {k: v.detach() for k, v in st.params.items()}, mu)
     return float(loss), norms
+
+
+def adabelief_step(p, g, m, v, step, lr, betas, eps, weight_decay):
+    """PARITY UNPINNED.  The reference's default optimizer (functions/__init__.py:24-42) is `clip_opt.AdaBelief` from the
+    un-vendored submodule External/step-clip-optimizer (no source in the reference tree, no pinned revision).  This
+    restates the published AdaBelief update (Zhuang et al., NeurIPS 2020, Algorithm 2) with the flags the reference passes:
+    weight_decouple=True, fixed_decay=False, rectify=False, amsgrad=False, clip_step=None.  In place on (p, m, v)."""
+    b1, b2 = betas
+    p.mul_(1.0 - lr * weight_decay)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    r = g - m
+    v.mul_(b2).addcmul_(r, r, value=1 - b2).add_(eps)
+    denom = (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))

@@ -241,5 +241,21 @@ def test_fused_adam_and_clip_match_torch():
             ref.step(); ours.step(); sch_ref.step(); sch.step()
             for pc, pg in zip(ps_cpu, ps_gpu):
                 assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=3e-6, atol=3e-7), (decoupled, it)
+    # AdaBelief (the reference's default group): published algorithm, parity unpinned (source absent upstream)
+    ps_cpu = [synth.gaussian(f"ab.p{i}", s) * 0.3 for i, s in enumerate(shapes)]
+    ps_gpu = [torch.nn.Parameter(p.clone().cuda()) for p in ps_cpu]
+    ms, vs = [torch.zeros_like(p) for p in ps_cpu], [torch.zeros_like(p) for p in ps_cpu]
+    cfg = configs.dict2namespace(dict(optimizer="AdaBelief", lr=3e-4, weight_decay=1e-5, beta=[0.9, 0.999], amsgrad=False, eps=1e-8,
+                                      clip_step=None, norm_ord=2, warmup=1000))
+    ours = O.get_optimizer(cfg, ps_gpu)
+    for it in range(1, 5):
+        for i, (pc, pg) in enumerate(zip(ps_cpu, ps_gpu)):
+            g = synth.gaussian(f"ab.g{it}.{i}", tuple(pc.shape)) * 0.05
+            pg.grad = g.clone().cuda()
+            ref_cpu.adabelief_step(pc, g, ms[i], vs[i], it, 3e-4, (0.9, 0.999), 1e-8, 1e-5)
+        ours.step()
+        for pc, pg in zip(ps_cpu, ps_gpu):
+            assert torch.allclose(pg.detach().cpu(), pc, rtol=3e-6, atol=3e-7), it
     with pytest.raises(NotImplementedError):
-        O.get_optimizer(configs.dict2namespace(dict(optimizer="AdaBelief")), ps_gpu)
+        O.get_optimizer(configs.dict2namespace(dict(optimizer="AdaBelief", lr=1e-3, weight_decay=0.0, beta=[0.9, 0.999], amsgrad=False,
+                                                    eps=1e-8, clip_step=0.1)), ps_gpu)
