@@ -117,6 +117,50 @@ def cpu_baseline(T, iters=3, batch=2):
                 sample=f"{iters} DDIM iterations x batch {batch} at T={T} (oracle/ref_cpu.py, fp32, {cores} threads), {dt:.1f} s")
 
 
+def training_leg(args, cfg, dev, rank, world, backend, steps=3):
+    """Secondary measurement (never the headline `value`): BASELINE config 4's training step -- noise + antithetic t,
+    loss, backward of the whole network, clip, fused AdamW (both groups), EMA -- at `--train-batch` samples per GPU, data
+    parallel over the ranks (one all-reduce of the flat gradient buffer per step).  Failures are reported, not raised."""
+    import torch.distributed as dist
+    try:
+        import copy
+        import ddim_audio_amd as D
+        from ddim_audio_amd import configs, dist as ddist, schedule, synth, train
+        tcfg = copy.deepcopy(cfg)
+        tcfg.optimization.optimizer.default.optimizer = "AdamW"  # reference-pinned optimizer for both groups
+        m = synth.fill_module(D.Model(tcfg))
+        if world > 1:
+            ddist.attach_grad_sync(m)
+        state = train.TrainingState(tcfg, m)
+        alphas = schedule.make_schedule(tcfg.diffusion)[1].to(dev)
+        b = args.train_batch
+        x = torch.randn(b, 2, args.t_size, tcfg.model.f_size, device=dev)
+        for _ in range(2):
+            train.train_step(m, x, state, alphas)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _ = train.train_step(m, x, state, alphas)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dt = float(el.item()) / steps
+        res = {"value": world * b / dt, "unit": "train samples/s", "ms_per_step": dt * 1e3, "batch_per_gpu": b, "t_size": args.t_size,
+               "steps": steps, "optimizer": "fused AdamW (both groups), clip 1.0, EMA 0.9999", "loss_finite": bool(torch.isfinite(loss)),
+               "model_tflops": world * b * 3 * 159.22e9 * args.t_size / 1024.0 / dt / 1e12,
+               "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+        del m, state, x
+        torch.cuda.empty_cache()
+        return res
+    except Exception as ex:  # the headline measurement above must survive a failure here
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +171,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU of the training leg (BASELINE config 4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,6 +237,10 @@ def main():
     elapsed = float(et.item())
     finite = bool(torch.isfinite(x).all().item())
 
+    train_leg = None
+    if not args.no_train_leg and os.environ.get("DDIMX_BENCH_TRAIN", "1") != "0":
+        train_leg = training_leg(args, cfg, dev, rank, world, backend)
+
     if rank == 0:
         iters_per_s = args.steps / elapsed
         out = {
@@ -240,6 +290,8 @@ def main():
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T)
+        if train_leg is not None:
+            out["train_step"] = train_leg
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
