@@ -428,6 +428,7 @@ static void wgrad_plan(const WgradGeom& g, int B, int Hd, int Wd, int* tiles_x, 
     *tiles_y = cdiv(Hd, g.th);
     const int total = B * *tiles_x * *tiles_y;
     int want = 512 / g.grid_y;
+    if (const char* e = getenv("DDIMX_WGRAD_SPLIT")) { const int v = atoi(e); if (v > 0) want = v / g.grid_y; }  // tuning hook
     if (want < 1) want = 1;
     if (want > total) want = total;
     *per = cdiv(total, want);

@@ -48,7 +48,9 @@ struct WgCfg {
     static constexpr int NBO = CO / 32, NBI = CI / 32;
     static constexpr int NCO = NBO <= 3 ? NBO : 2;
     static constexpr int NCI = NCO == 3 ? 1 : (NBI % 2 == 0 ? 2 : 1);
-    static constexpr int TS = MODE == DOWN4 ? 2 : 1;           // tap halves handled by different waves
+    // taps are split over waves: DOWN4 halves (8 + 8); CONV3 with a single block pair thirds (3 + 3 + 3: 48 accumulator
+    // registers per wave instead of 144, so several workgroups share a CU and overlap staging with MFMAs)
+    static constexpr int TS = MODE == DOWN4 ? 2 : (NBO * NBI == 1 ? 3 : 1);
     static constexpr int NTAPS = MODE == DOWN4 ? 16 : 9;
     static constexpr int TAPW = MODE == DOWN4 ? 4 : 3;
     static constexpr int TPW = NTAPS / TS;                     // taps (accumulator tiles) per wave
