@@ -624,25 +624,33 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
     if (n_params != (int)h->specs.size()) return fail("ddimx_pack_weights: got %d tensors, plan has %zu", n_params, h->specs.size());
     hipStream_t s = (hipStream_t)stream;
     const int C5 = h->cfg.ch[h->L - 1], Fr = h->Fr;
+    PackCopyBatch batch;  // plain copies (norm weights, biases, dense matrices) go out in batches of kMax per launch
+    batch.count = 0;
+    auto push_copy = [&](const float* src, float* dst, long long n) -> hipError_t {
+        batch.src[batch.count] = src; batch.dst[batch.count] = dst; batch.n[batch.count] = n;
+        if (++batch.count == PackCopyBatch::kMax) { hipError_t e = pack_copy_multi_launch(batch, s); batch.count = 0; return e; }
+        return hipSuccess;
+    };
     for (int i = 0; i < n_params; ++i) {
         const ParamSpec& p = h->specs[i];
         const float* src = (const float*)params[i];
         void* dst = (char*)packed + p.off;
         if (!src) return fail("ddimx_pack_weights: parameter %d (%s) is null", i, p.name.c_str());
         switch (p.kind) {
-            case PK_COPY: HIPCHK(pack_copy_launch(src, (float*)dst, p.numel, s)); break;
+            case PK_COPY: HIPCHK(push_copy(src, (float*)dst, p.numel)); break;
             case PK_CONV: HIPCHK(pack_conv_launch(h->dtype, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
             case PK_CONV_F32: HIPCHK(pack_conv_launch(DT_F32, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
             case PK_CONVT: HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s)); break;
             case PK_BIAS2:
-                HIPCHK(pack_copy_launch(src, (float*)dst, p.d0, s));
-                HIPCHK(pack_copy_launch(src, (float*)dst + p.d0, p.d0, s));
+                HIPCHK(push_copy(src, (float*)dst, p.d0));
+                HIPCHK(push_copy(src, (float*)dst + p.d0, p.d0));
                 break;
             case PK_PERM_COLS: HIPCHK(pack_perm_cols_launch(src, (float*)dst, p.d0, C5, Fr, s)); break;
             case PK_PERM_ROWS: HIPCHK(pack_perm_rows_launch(src, (float*)dst, C5, Fr, p.d1, s)); break;
             default: return fail("bad pack kind");
         }
     }
+    HIPCHK(pack_copy_multi_launch(batch, s));
     return 0;
 }
 

@@ -91,6 +91,11 @@ hipError_t scale_multi_launch(const long long* ptrs, const long long* sizes, con
 
 // ---- weight packing ------------------------------------------------------------------------------------
 hipError_t pack_copy_launch(const float* src, float* dst, long long n, hipStream_t s);
+struct PackCopyBatch {
+    static constexpr int kMax = 96;
+    const float* src[kMax]; float* dst[kMax]; long long n[kMax]; int count;
+};
+hipError_t pack_copy_multi_launch(const PackCopyBatch& b, hipStream_t s);
 hipError_t pack_conv_launch(int dtype, const float* w /*[O][I][KH][KW]*/, void* dst /*[KH*KW][O][I]*/, int O, int I,
                             int KH, int KW, hipStream_t s);
 hipError_t pack_convT_launch(int dtype, const float* w /*[I][O][4][4]*/, void* dst /*[2][6][2*O][I]*/, int I, int O,

@@ -898,6 +898,22 @@ hipError_t pack_copy_launch(const float* src, float* dst, long long n, hipStream
     return hipGetLastError();
 }
 
+// many small fp32 copies in one launch: the (src, dst, n) triples travel as kernel arguments
+__global__ void __launch_bounds__(256) pack_copy_multi_kernel(const PackCopyBatch b) {
+    const float* src = b.src[blockIdx.y];
+    float* dst = b.dst[blockIdx.y];
+    const long long n = b.n[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+hipError_t pack_copy_multi_launch(const PackCopyBatch& b, hipStream_t s) {
+    if (b.count < 1) return hipSuccess;
+    long long mx = 0;
+    for (int i = 0; i < b.count; ++i) if (b.n[i] > mx) mx = b.n[i];
+    const int bx = (int)((mx + 255) / 256 < 256 ? (mx + 255) / 256 : 256);
+    hipLaunchKernelGGL(pack_copy_multi_kernel, dim3(bx, b.count), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
 template <typename T>
 __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ dst, int O, int I, int KK) {
     const long long n = (long long)KK * O * I;

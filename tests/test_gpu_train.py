@@ -177,3 +177,31 @@ def test_dropout_training_mode():
     m.invalidate()
     fd = (vals[0] - vals[1]) / (2 * h)
     assert abs(fd - want) <= 2e-2 * abs(want) + 1e-3, (fd, want)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["f32", "bf16"])
+def test_model_backward_ragged_shape_vs_oracle(mode):
+    """Odd batch and a T whose bottleneck length is not a power of two (ragged conv tiles, ragged weight-gradient tiles,
+    non-power-of-two DFT): loss and gradients against autograd through the CPU oracle."""
+    dtype_str, dt = mode
+    cfg, m = _train_model("tiny", dtype_str, 5)
+    _, alphas = make_schedule(cfg.diffusion)
+    shape = (3, 2, 24, 32)
+    x0, e = synth.gaussian("ragged.x0", shape), synth.gaussian("ragged.e", shape)
+    t = torch.tensor([0, 999, 412])
+    loss = losses.noise_estimation_loss(m, x0.cuda(), t.cuda(), e.cuda(), alphas.cuda())
+    loss.backward()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "temb.te"}
+    live = dict(params, **{"temb.te": sd["temb.te"]})
+    ocfg = configs.dict2namespace(configs.tiny_dict("torch.FloatTensor"))
+    want = ref_cpu.noise_estimation_loss(lambda a, b: ref_cpu.model_forward(live, ocfg, a, b), x0, t, e, alphas)
+    want.backward()
+    assert abs(float(loss) - float(want)) <= (1e-5 if dt == G.F32 else 2e-3) * float(want)
+    total = sum(float(p.grad.double().square().sum()) for p in params.values()) ** 0.5
+    for name, p in m.named_parameters():
+        ref = params[name].grad
+        got = p.grad.detach().cpu()
+        scale = max(float(ref.double().square().mean().sqrt()), 1e-4 * total / ref.numel() ** 0.5)
+        err = float((got - ref).abs().max()) / scale
+        assert err <= (2e-3 if dt == G.F32 else 0.6), f"{name}: {err:.3e} x rms"
