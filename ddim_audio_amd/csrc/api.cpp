@@ -858,7 +858,7 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
         }
     }
     {
-        const size_t q = edge_wgrad_partial_floats(B, f.ch[0], f.in_channels, T, f.f_size);
+        const size_t q = edge_wgrad_partial_floats(dt, B, f.ch[0], f.in_channels, T, f.f_size);
         if (q > part_f) part_f = q;
     }
     w->gA = cv.take((size_t)B * T * f.f_size * f.ch[0] * es);

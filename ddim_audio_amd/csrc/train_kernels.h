@@ -49,7 +49,7 @@ hipError_t linear_bwd_x_launch(const float* dy, const float* W, const float* xpr
 // ---- edge convolutions -----------------------------------------------------------------------------------------
 hipError_t conv_out_bwd_data_launch(int dtype, const float* d_eps, const float* w /*packed [9][cout][C0]*/, void* ds, int B, int C0,
                                     int cout, int H, int W, hipStream_t s);
-size_t edge_wgrad_partial_floats(int B, int C, int NI, int H, int W);
+size_t edge_wgrad_partial_floats(int dtype, int B, int C, int NI, int H, int W);
 // mode 0: input conv (G = d hidden[0], S = x); mode 1: output conv (G = g1 + g2 = x + hidden[0], S = d_eps)
 hipError_t edge_wgrad_launch(int dtype, int mode, const void* g1, const void* g2, const float* S, float* partial, float* dW,
                              float* db, int B, int C, int NI, int H, int W, hipStream_t s);

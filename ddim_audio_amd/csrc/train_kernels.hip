@@ -737,95 +737,118 @@ __global__ void __launch_bounds__(288) edge_wgrad_kernel(const T* __restrict__ g
     if (tid < C) out[9 * NI * C + tid] = sumg;
     else if (tid - C < NI) out[9 * NI * C + C + tid - C] = sums;
 }
-// Fast path for the reference shape (C = 32 channels, NI <= 2 planes): no LDS in the loop.  A wave owns a strip of 8
-// columns x `rows` rows of one sample; lane = (channel lane & 31, plane lane >> 5).  The three S rows around the current
-// row live in registers (10 values each, one new row per step), G is read once per pixel: 72 FMAs per lane and row
-// against 18 small loads.  The block's four waves fold their 9 accumulators through LDS into one partial slab.
-constexpr int kStripW = 8;
+// Fast path for the reference shape (C = 32 channels, NI = 2 planes).  A block owns a strip of PIXB columns x `rows`
+// rows of one sample; thread = (pixel column, 16-byte channel piece): G is read with one 16-byte load per pixel, the
+// 3x3xNI neighbourhood of S comes from an LDS tile (staged 32 rows at a time), and each thread keeps EPB x 9 x NI
+// accumulators in registers for the whole strip.  The pixel lanes are folded at the end (wave shuffles, then LDS).
+constexpr int kEdgeChunk = 32;  // rows of S staged per LDS tile
 template <typename T>
 __global__ void __launch_bounds__(256) edge_wgrad_strip_kernel(const T* __restrict__ g1, const T* __restrict__ g2,
-                                                               const float* __restrict__ S, float* __restrict__ partial, int NI,
-                                                               int H, int W, int rows, int sx, int sy, int total_strips) {
-    constexpr int C = 32;
-    __shared__ float red[4][11][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 31, pl = lane >> 5;
-    const int strip = blockIdx.x * 4 + wave;
-    float acc[9];
+                                                               const float* __restrict__ S, float* __restrict__ partial, int H,
+                                                               int W, int rows, int sx, int sy) {
+    constexpr int C = 32, NI = 2, EPB = Piece<T>::N, PPB = C / EPB, PIXB = 256 / PPB, SW = PIXB + 2;
+    constexpr int NACC = EPB * 9 * NI;
+    __shared__ float St[NI][kEdgeChunk + 2][SW];
+    __shared__ float red[4][PPB][NACC + EPB + NI];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = tid % PPB, p = tid / PPB;
+    const int strip = blockIdx.x;
+    const int b = strip / (sx * sy), x0 = (strip % sx) * PIXB, y0 = ((strip / sx) % sy) * rows;
+    const int y1 = y0 + rows < H ? y0 + rows : H;
+    float acc[NACC];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    float sumg = 0.f, sums = 0.f;
-    if (strip < total_strips && pl < NI) {
-        const int b = strip / (sx * sy), x0 = (strip % sx) * kStripW, y0 = ((strip / sx) % sy) * rows;
-        const int y1 = y0 + rows < H ? y0 + rows : H;
-        const float* Sp = S + ((size_t)b * NI + pl) * H * W;
-        float r0[10], r1[10], r2[10];
-        // unconditional loads at clamped coordinates, zeroed by select afterwards: all loads of a row issue back to back
-        auto load_row = [&](int y, float (&r)[10]) __attribute__((always_inline)) {
-            const bool yok = y >= 0 && y < H;
-            const float* rowp = Sp + (size_t)(yok ? y : 0) * W;
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    float sumg[EPB], sums[NI];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const int x = x0 - 1 + j;
-                const bool ok = yok && x >= 0 && x < W;
-                const float v = rowp[ok ? x : 0];
-                r[j] = ok ? v : 0.f;
-            }
-        };
-        // G row (8 pixels of this lane's channel); loads are unconditional at clamped coordinates
-        auto load_g = [&](int y, float (&gr)[kStripW]) __attribute__((always_inline)) {
-            const bool yok = y < y1;
-            const size_t rowe = (((size_t)b * H + (yok ? y : y0)) * W + x0) * C + c;
+    for (int e = 0; e < EPB; ++e) sumg[e] = 0.f;
 #pragma unroll
-            for (int px = 0; px < kStripW; ++px) {
-                const bool ok = yok && x0 + px < W;
-                const size_t e = ok ? rowe + (size_t)px * C : rowe;
-                float v = to_f<T>(g1[e]);
-                if (g2) v += to_f<T>(g2[e]);
-                gr[px] = ok ? v : 0.f;
-            }
-        };
-        float gc[kStripW], gn[kStripW], r3[10];
-        load_row(y0 - 1, r0);
-        load_row(y0, r1);
-        load_row(y0 + 1, r2);
-        load_g(y0, gc);
+    for (int i = 0; i < NI; ++i) sums[i] = 0.f;
+    const int x = x0 + p;
+    const bool xok = x < W;
+    for (int yc = y0; yc < y1; yc += kEdgeChunk) {
+        const int nr = y1 - yc < kEdgeChunk ? y1 - yc : kEdgeChunk;
+        __syncthreads();
+        for (int i = tid; i < NI * (kEdgeChunk + 2) * SW; i += 256) {
+            const int cx = i % SW, ry = (i / SW) % (kEdgeChunk + 2), pl = i / (SW * (kEdgeChunk + 2));
+            const int gy = yc - 1 + ry, gx = x0 - 1 + cx;
+            const bool ok = ry < nr + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float v = S[(((size_t)b * NI + pl) * H + (ok ? gy : 0)) * W + (ok ? gx : 0)];
+            St[pl][ry][cx] = ok ? v : 0.f;
+        }
+        __syncthreads();
+        // G pieces are requested one row ahead of their use (clamped address, masked after the load)
+        const size_t ebase = (((size_t)b * H + yc) * W + (xok ? x : x0)) * C + j * EPB;
+        const size_t rstride = (size_t)W * C;
+        uint4 n1 = *(const uint4*)(g1 + ebase), n2 = make_uint4(0, 0, 0, 0);
+        if (g2) n2 = *(const uint4*)(g2 + ebase);
 #pragma unroll 1
-        for (int y = y0; y < y1; ++y) {
-            // the next row's operands are requested before this row's arithmetic (one row in flight per wave)
-            load_row(y + 2, r3);
-            load_g(y + 1, gn);
+        for (int r = 0; r < nr; ++r) {
+            const uint4 c1 = n1, c2 = n2;
+            const size_t en = ebase + (size_t)(r + 1 < nr ? r + 1 : r) * rstride;
+            n1 = *(const uint4*)(g1 + en);
+            if (g2) n2 = *(const uint4*)(g2 + en);
+            float g[EPB];
+            Piece<T>::unpack(c1, g);
+            if (g2) {
+                float g2v[EPB];
+                Piece<T>::unpack(c2, g2v);
 #pragma unroll
-            for (int px = 0; px < kStripW; ++px) {
-                const float gv = gc[px];
-                sumg += gv;
-                sums += (x0 + px < W) ? r1[px + 1] : 0.f;
+                for (int q = 0; q < EPB; ++q) g[q] += g2v[q];
+            }
+            if (!xok) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    acc[kx] = fmaf(gv, r0[px + kx], acc[kx]);
-                    acc[3 + kx] = fmaf(gv, r1[px + kx], acc[3 + kx]);
-                    acc[6 + kx] = fmaf(gv, r2[px + kx], acc[6 + kx]);
+                for (int q = 0; q < EPB; ++q) g[q] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < EPB; ++q) sumg[q] += g[q];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (xok) sums[i] += St[i][r + 1][p + 1];
+#pragma unroll
+                for (int kk = 0; kk < 9; ++kk) {
+                    const float sv = St[i][r + kk / 3][p + kk % 3];
+#pragma unroll
+                    for (int q = 0; q < EPB; ++q) acc[(q * 9 + kk) * NI + i] = fmaf(g[q], sv, acc[(q * 9 + kk) * NI + i]);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 10; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; r2[j] = r3[j]; }
-#pragma unroll
-            for (int px = 0; px < kStripW; ++px) gc[px] = gn[px];
         }
     }
+    // fold the pixel lanes of a wave (lanes with equal j: xor over the lane bits above log2(PPB)), then the 4 waves
+    auto fold = [&](float v) __attribute__((always_inline)) -> float {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) red[wave][k][lane] = acc[k];
-    red[wave][9][lane] = sumg;
-    red[wave][10][lane] = sums;
+        for (int o = PPB; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = fold(acc[k]);
+#pragma unroll
+    for (int q = 0; q < EPB; ++q) sumg[q] = fold(sumg[q]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) sums[i] = fold(sums[i]);
     __syncthreads();
-    if (wave == 0 && pl < NI) {
-        float* out = partial + (size_t)blockIdx.x * (9 * NI * C + C + NI);
+    if (lane < PPB) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-            out[(k * NI + pl) * C + c] = (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
-        if (pl == 0) out[9 * NI * C + c] = (red[0][9][lane] + red[1][9][lane]) + (red[2][9][lane] + red[3][9][lane]);
-        if (c == 0) out[9 * NI * C + C + pl] = (red[0][10][lane] + red[1][10][lane]) + (red[2][10][lane] + red[3][10][lane]);
+        for (int k = 0; k < NACC; ++k) red[wave][lane][k] = acc[k];
+#pragma unroll
+        for (int q = 0; q < EPB; ++q) red[wave][lane][NACC + q] = sumg[q];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) red[wave][lane][NACC + EPB + i] = sums[i];
     }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * (9 * NI * C + C + NI);
+    for (int k = tid; k < PPB * (NACC + EPB); k += 256) {
+        const int jj = k / (NACC + EPB), r = k % (NACC + EPB);
+        const float v = (red[0][jj][r] + red[1][jj][r]) + (red[2][jj][r] + red[3][jj][r]);
+        if (r < NACC) {
+            const int i = r % NI, kk = (r / NI) % 9, q = r / (NI * 9);
+            out[(kk * NI + i) * C + jj * EPB + q] = v;
+        } else {
+            out[9 * NI * C + jj * EPB + (r - NACC)] = v;
+        }
+    }
+    if (tid < NI)  // every piece lane of a pixel added the same S values: take piece 0
+        out[9 * NI * C + C + tid] = (red[0][0][NACC + EPB + tid] + red[1][0][NACC + EPB + tid]) +
+                                    (red[2][0][NACC + EPB + tid] + red[3][0][NACC + EPB + tid]);
 }
 
 // mode 0 (input conv): dW[c][i][kk], db[c] = sumG;  mode 1 (output conv): dW[i][c][kk] = R[8-kk], db[i] = sumS
@@ -853,30 +876,32 @@ __global__ void __launch_bounds__(256) edge_wgrad_reduce_kernel(const float* __r
     }
 }
 constexpr int kStripRows = 128;
-static inline bool edge_fast(int C, int NI) { return C == 32 && NI <= 2; }
-int edge_wgrad_nblocks(int B, int C, int NI, int H, int W) {
+static inline bool edge_fast(int C, int NI) { return C == 32 && NI == 2; }
+static inline int edge_pixb(int dtype) { return dtype == DT_BF16 ? 64 : 32; }
+int edge_wgrad_nblocks(int dtype, int B, int C, int NI, int H, int W) {
     if (edge_fast(C, NI)) {
-        const long long strips = (long long)B * ((W + kStripW - 1) / kStripW) * ((H + kStripRows - 1) / kStripRows);
-        return (int)((strips + 3) / 4);
+        const int pb = edge_pixb(dtype);
+        return (int)((long long)B * ((W + pb - 1) / pb) * ((H + kStripRows - 1) / kStripRows));
     }
     const long long t = (long long)B * ((H + kEdgeT - 1) / kEdgeT) * ((W + kEdgeT - 1) / kEdgeT);
     return (int)(t < 1024 ? t : 1024);
 }
-size_t edge_wgrad_partial_floats(int B, int C, int NI, int H, int W) {
-    return (size_t)edge_wgrad_nblocks(B, C, NI, H, W) * (9 * NI * C + C + NI);
+size_t edge_wgrad_partial_floats(int dtype, int B, int C, int NI, int H, int W) {
+    return (size_t)edge_wgrad_nblocks(dtype, B, C, NI, H, W) * (9 * NI * C + C + NI);
 }
 hipError_t edge_wgrad_launch(int dtype, int mode, const void* g1, const void* g2, const float* S, float* partial, float* dW,
                              float* db, int B, int C, int NI, int H, int W, hipStream_t s) {
     if (NI > 4 || 9 * C > 2 * 288 || C + NI > 288) return hipErrorInvalidValue;
-    const int nb = edge_wgrad_nblocks(B, C, NI, H, W);
+    const int nb = edge_wgrad_nblocks(dtype, B, C, NI, H, W);
     if (edge_fast(C, NI)) {
-        const int sx = (W + kStripW - 1) / kStripW, sy = (H + kStripRows - 1) / kStripRows;
+        const int pb = edge_pixb(dtype);
+        const int sx = (W + pb - 1) / pb, sy = (H + kStripRows - 1) / kStripRows;
         if (dtype == DT_BF16)
             hipLaunchKernelGGL(edge_wgrad_strip_kernel<__bf16>, dim3(nb), dim3(256), 0, s, (const __bf16*)g1, (const __bf16*)g2, S, partial,
-                               NI, H, W, kStripRows, sx, sy, B * sx * sy);
+                               H, W, kStripRows, sx, sy);
         else
             hipLaunchKernelGGL(edge_wgrad_strip_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)g1, (const float*)g2, S, partial,
-                               NI, H, W, kStripRows, sx, sy, B * sx * sy);
+                               H, W, kStripRows, sx, sy);
     } else {
         const int tx = (W + kEdgeT - 1) / kEdgeT, ty = (H + kEdgeT - 1) / kEdgeT;
         const size_t lds = (size_t)(256 * (C + 1) + NI * 324) * 4;

@@ -407,7 +407,9 @@ class Model(_Node):
 
     # -- forward -------------------------------------------------------------------------------------
     def forward(self, input, t):
-        """input [B, C, T, F] fp32 on the GPU, t [B] int64 -> eps [B, C, T, F] fp32 (reference :237-294, eval)."""
+        """input [B, C, T, F] fp32 on the GPU, t [B] int64 -> eps [B, C, T, F] fp32 (reference :237-294).
+        eval mode or no_grad: ``ddimx_unet_fwd``.  train mode with grad enabled: ``ddimx_unet_fwd_train`` (dropout active,
+        tape kept) as an autograd node whose backward fills every parameter's gradient (``ddimx_unet_bwd``)."""
         from . import _lib
         if not input.is_cuda:
             raise RuntimeError("ddim_audio_amd.Model computes only through libddimx on a ROCm GPU; got a CPU tensor "
