@@ -470,7 +470,18 @@ struct RBGrads {
 struct RBBwdWs {
     void *du, *dg;          // activation-sized
     float *stats, *coef, *dgb, *sums, *partial;
+    // whole-network backward: the batch sums of the per-sample parameter-gradient terms are deferred and flushed many at
+    // a time (colsum_multi); each block then gets its own 4 slots of [B][2][C] floats in `slots` (null: sum immediately)
+    ColsumBatch* defer = nullptr;
+    float* slots = nullptr;
 };
+static int push_colsum(const RBBwdWs& w, const float* src, int B, long long stride, int C, float* dst, hipStream_t s) {
+    if (!w.defer) { HIPCHK(colsum_launch(src, B, stride, C, dst, s)); return 0; }
+    ColsumBatch& q = *w.defer;
+    q.src[q.count] = src; q.dst[q.count] = dst; q.stride[q.count] = stride; q.B[q.count] = B; q.C[q.count] = C;
+    ++q.count;  // the caller flushes before the slots are reused (capacity is checked there)
+    return 0;
+}
 static size_t rb_bwd_stats_floats(int dtype, int B, int HW, int C) { return (size_t)B * resid_nparts(dtype, HW, C) * C * 2; }
 
 // Backward of Residual_Block (autograd of models/diffusion.py:42-56).  dy -> dx (+ extra if given); parameter
@@ -481,22 +492,28 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     const int HW = H * W;
     const double cnt = (double)HW * (C / kGroups);
     const int np = resid_nparts(dtype, HW, C);
+    float* const slot0 = w.slots ? w.slots : w.dgb;  // [B][2][C] each; with deferral every use keeps its own slot
+    const size_t slot_f = (size_t)B * 2 * C;
+    float* const dgb2 = slot0;
+    float* const sumb = w.slots ? slot0 + slot_f : w.dgb;
+    float* const dgb1 = w.slots ? slot0 + 2 * slot_f : w.dgb;
+    float* const dgb0 = w.slots ? slot0 + 3 * slot_f : w.dgb;
     // ---- GN2 (fed by SiLU(u2), weight only) and the SiLU in front of it: du2
     HIPCHK(gn_bwd_stats_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.stats, B, HW, C, s));
-    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam2, tp.mr(2, B, C), w.coef, w.dgb, B, s));
-    HIPCHK(colsum_launch(w.dgb, B, 2 * C, C, gr.g2, s));
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam2, tp.mr(2, B, C), w.coef, dgb2, B, s));
+    CHK(push_colsum(w, dgb2, B, 2 * C, C, gr.g2, s));
     HIPCHK(gn_bwd_apply_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.coef, nullptr, nullptr, w.du, w.sums, B, HW, C, s));
-    HIPCHK(partsum_launch(w.sums, B, np, C, w.dgb, C, s));          // per-sample channel sums of du2
-    HIPCHK(colsum_launch(w.dgb, B, C, C, gr.bias1, s));            // conv.1.bias
+    HIPCHK(partsum_launch(w.sums, B, np, C, sumb, C, s));           // per-sample channel sums of du2
+    CHK(push_colsum(w, sumb, B, C, C, gr.bias1, s));                // conv.1.bias
     // ---- conv.1: weight gradient against GN1(SiLU(u1)), data gradient -> dg
     CHK(run_wgrad(dtype, CONV3, C, C, tp.u1, w.du, tp.sc(1, B, C), tp.sh(1, B, C), XF_SILU_AFFINE, w.partial, gr.w1, B, H, W, s));
     ConvCall d1 = {dtype, CONV3, C, C, w.du, wd1, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
     CHK(run_conv(d1, s, nullptr, nullptr));
     // ---- GN1 (fed by SiLU(u1)) and the SiLU in front of it: du1
     HIPCHK(gn_bwd_stats_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.stats, B, HW, C, s));
-    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam1, tp.mr(1, B, C), w.coef, w.dgb, B, s));
-    HIPCHK(colsum_launch(w.dgb, B, 2 * C, C, gr.g1, s));
-    HIPCHK(colsum_launch(w.dgb + C, B, 2 * C, C, gr.b1, s));
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam1, tp.mr(1, B, C), w.coef, dgb1, B, s));
+    CHK(push_colsum(w, dgb1, B, 2 * C, C, gr.g1, s));
+    CHK(push_colsum(w, dgb1 + C, B, 2 * C, C, gr.b1, s));
     HIPCHK(gn_bwd_apply_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.coef, nullptr, nullptr, w.du, w.sums, B, HW, C, s));
     if (gr.dtemb) HIPCHK(partsum_launch(w.sums, B, np, C, gr.dtemb, gr.dtemb_stride, s));  // timestep-embedding chunk
     // ---- conv.0: weight gradient against SiLU(GN0(x)), data gradient -> dg
@@ -505,9 +522,9 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     CHK(run_conv(d0, s, nullptr, nullptr));
     // ---- SiLU behind GN0, GN0 itself, and the identity path
     HIPCHK(gn_bwd_stats_launch(dtype, 1, w.dg, x, tp.sc(0, B, C), tp.sh(0, B, C), w.stats, B, HW, C, s));
-    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam0, tp.mr(0, B, C), w.coef, w.dgb, B, s));
-    HIPCHK(colsum_launch(w.dgb, B, 2 * C, C, gr.g0, s));
-    HIPCHK(colsum_launch(w.dgb + C, B, 2 * C, C, gr.b0, s));
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam0, tp.mr(0, B, C), w.coef, dgb0, B, s));
+    CHK(push_colsum(w, dgb0, B, 2 * C, C, gr.g0, s));
+    CHK(push_colsum(w, dgb0 + C, B, 2 * C, C, gr.b0, s));
     HIPCHK(gn_bwd_apply_launch(dtype, 1, w.dg, x, dy, extra, w.coef, tp.sc(0, B, C), tp.sh(0, B, C), dx, nullptr, B, HW, C, s));
     return 0;
 }
@@ -816,13 +833,15 @@ static void carve_tape(const ddimx_ctx* c, char* base, int B, int T, TrainTape* 
     t->total = cv.off;
 }
 
+// Residual blocks whose deferred batch sums fit one ColsumBatch (7 entries each)
+constexpr int kDeferBlocks = ColsumBatch::kMax / 7;
 // Scratch shared by the training forward and the backward.
 struct TrainWs {
     float *stats, *scale, *shift;
     float *Ut, *Hb, *O, *gpart;
     std::vector<void*> Ga, Gb, GS;
     void *gA, *du, *dg;
-    float *coef, *dgb, *sums, *partial;
+    float *coef, *dgb, *sums, *partial, *slots;
     float *dtemb, *dh2, *dh1;
     float *dO, *dXa, *dXb, *dZ, *dH, *T1, *T2, *lnpart, *dTok, *pgrad;
     size_t total;
@@ -869,6 +888,7 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
     w->shift = (float*)cv.take((size_t)B * cmax * 4);
     w->coef = (float*)cv.take((size_t)B * 3 * cmax * 4);
     w->dgb = (float*)cv.take((size_t)B * 2 * cmax * 4);
+    w->slots = (float*)cv.take((size_t)kDeferBlocks * 4 * B * 2 * cmax * 4);
     w->sums = (float*)cv.take(sums_f * 4);
     w->partial = (float*)cv.take(part_f * 4);
     w->dtemb = (float*)cv.take((size_t)B * c->E * 4);
@@ -1125,6 +1145,22 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
     }
     auto G = [&](int i) { return grads + goff[i]; };
     RBBwdWs rw = {w.du, w.dg, w.stats, w.coef, w.dgb, w.sums, w.partial};
+    ColsumBatch defer;
+    defer.count = 0;
+    rw.defer = &defer;
+    int deferred_blocks = 0;
+    int cmax = 0;
+    for (int l = 0; l < L; ++l) if (f.ch[l] > cmax) cmax = f.ch[l];
+    auto next_slots = [&]() -> int {  // hands the next block its slots; flushes the batch when the arena is full
+        if (deferred_blocks == kDeferBlocks) {
+            HIPCHK(colsum_multi_launch(defer, s));
+            defer.count = 0;
+            deferred_blocks = 0;
+        }
+        rw.slots = w.slots + (size_t)deferred_blocks * 4 * B * 2 * cmax;
+        ++deferred_blocks;
+        return 0;
+    };
     auto rb_grads = [&](const RBW& r, float* dtemb) {
         RBGrads g = {G(r.g0), G(r.b0), G(r.g1), G(r.b1), G(r.g2), G(r.w0), G(r.w1), G(r.bias1), dtemb, c->E};
         return g;
@@ -1142,6 +1178,7 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
             const void* xin = r ? tp.up_y[l][r - 1] : tp.up_in[l];
             void* dx = r == 0 ? w.GS[l] : (gy == w.Gb[l] ? w.Ga[l] : w.Gb[l]);
             const RBW& rbw = c->up_rb[l][r];
+            CHK(next_slots());
             CHK(run_resblock_bwd(dt, C, xin, tp.up_rb[l][r], gy, nullptr, dx, pf(c, packed, rbw.g0), pf(c, packed, rbw.g1),
                                  pf(c, packed, rbw.g2), pb + bp.up_wd0[l][r], pb + bp.up_wd1[l][r],
                                  rb_grads(rbw, w.dtemb + c->emb_off_up[up_bi(f, L, l, r)]), rw, B, H, W, s));
@@ -1227,6 +1264,7 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
             const void* xin = r ? tp.dn_y[l][r - 1] : tp.dn_in[l];
             void* dx = gy == w.Gb[l] ? w.Ga[l] : w.Gb[l];
             const RBW& rbw = c->down_rb[l][r];
+            CHK(next_slots());
             CHK(run_resblock_bwd(dt, C, xin, tp.dn_rb[l][r], gy, (l == 0 && r == 0) ? w.gA : nullptr, dx, pf(c, packed, rbw.g0),
                                  pf(c, packed, rbw.g1), pf(c, packed, rbw.g2), pb + bp.dn_wd0[l][r], pb + bp.dn_wd1[l][r],
                                  rb_grads(rbw, w.dtemb + c->emb_off_down[down_bi(f, l, r)]), rw, B, H, W, s));
@@ -1243,6 +1281,7 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
             gy = w.Ga[l - 1];
         }
     }
+    HIPCHK(colsum_multi_launch(defer, s));
     // ---- input conv (models/diffusion.py:255-256): gy = d(hidden[0]) including the skip into the output conv
     HIPCHK(edge_wgrad_launch(dt, 0, gy, nullptr, x, w.partial, G(c->in_w), G(c->in_b), B, f.ch[0], f.in_channels, T, f.f_size, s));
     // ---- timestep-embedding MLP

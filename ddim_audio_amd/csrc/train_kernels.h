@@ -18,6 +18,11 @@ hipError_t gn_bwd_apply_launch(int dtype, int mode, const void* g, const void* u
                                const float* coef, const float* scale, const float* shift, void* out, float* sums, int B,
                                int HW, int C, hipStream_t s);
 hipError_t colsum_launch(const float* src, int B, long long stride, int C, float* dst, hipStream_t s);
+struct ColsumBatch {
+    static constexpr int kMax = 96;
+    const float* src[kMax]; float* dst[kMax]; long long stride[kMax]; int B[kMax]; int C[kMax]; int count;
+};
+hipError_t colsum_multi_launch(const ColsumBatch& q, hipStream_t s);
 // dst[b][c] = sum_p src[((b*nparts + p)*C + c) * src_step]   (src_step = 2 reads the `sum` half of (sum, sumsq) slabs)
 hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s,
                           int src_step = 1);

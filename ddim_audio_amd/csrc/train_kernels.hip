@@ -192,6 +192,35 @@ hipError_t colsum_launch(const float* src, int B, long long stride, int C, float
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 31) / 32), dim3(256), 0, s, src, B, stride, C, dst);
     return hipGetLastError();
 }
+// the same for up to kMax (src, dst) pairs in one launch (the entries travel as kernel arguments): the backward defers
+// its per-block parameter-gradient batch sums and flushes them together
+__global__ void __launch_bounds__(256) colsum_multi_kernel(const ColsumBatch q) {
+    __shared__ double red[8][32];
+    const int e = blockIdx.y;
+    const int C = q.C[e], B = q.B[e];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    if (blockIdx.x * 32 >= C) return;  // uniform
+    const float* src = q.src[e];
+    const long long stride = q.stride[e];
+    double s = 0.0;
+    if (c < C)
+        for (int b = rl; b < B; b += 8) s += (double)src[(size_t)b * stride + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s = 0.0;
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        q.dst[e][c] = (float)s;
+    }
+}
+hipError_t colsum_multi_launch(const ColsumBatch& q, hipStream_t s) {
+    if (q.count < 1) return hipSuccess;
+    int mx = 0;
+    for (int i = 0; i < q.count; ++i) if (q.C[i] > mx) mx = q.C[i];
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((mx + 31) / 32, q.count), dim3(256), 0, s, q);
+    return hipGetLastError();
+}
 // dst[b][c] = sum_p src[((b*nparts + p)*C + c) * src_step]
 __global__ void __launch_bounds__(256) partsum_kernel(const float* __restrict__ src, int nparts, int C, float* __restrict__ dst,
                                                       long long dst_stride, int src_step) {
