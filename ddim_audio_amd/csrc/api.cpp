@@ -233,6 +233,11 @@ static int build_plan(ddimx_ctx* c) {
     return 0;
 }
 
+// Split-K of the FNet GEMMs is chosen from the PER-SAMPLE problem (rows of one sample, never the batch): a sample's rows are
+// then summed in the same order alone, inside any batch and on any number of GPUs (bit-identical results).
+constexpr int kMaxSplitK = 8;
+static inline int sample_splitk(int rows_per_sample, int N, int K, int bf16) { return gemm_pick_splitk(rows_per_sample, N, K, 1, bf16); }
+
 // ------------------------------------------------------------------------------------------ workspace
 struct Carver {
     char* base;
@@ -318,7 +323,7 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
                                {(int)M, inter, hid, 1, bf}, {(int)M, hid, inter, 1, bf}, {(int)M, c->width, hid, 1, bf}};
         size_t mx = 0;
         for (auto& q : shp) {
-            const size_t n = (size_t)gemm_pick_splitk(q[0], q[1], q[2], q[3], q[4]) * q[3] * q[0] * q[1];
+            const size_t n = (size_t)kMaxSplitK * q[3] * q[0] * q[1];  // the split depends on the per-sample shape only; size for the cap
             if (n > mx) mx = n;
         }
         w->gpart = (float*)cv.take(mx * 4);
@@ -557,13 +562,13 @@ static int run_temb(const float* te, const int64_t* t, const float* w0, const fl
 // Dense-weight GEMMs use bf16 MFMA in bf16 mode; the DFT factors always run on the exact fp32 MFMA.
 static int fnet_gemm(const Ws& w, hipStream_t s, const float* A, const float* Bm, float* C, int M, int N, int K, int lda,
                      int ldb, int ldc, const float* bias, const float* resid, int act, int accumulate, int bf16,
-                     int batch = 1, long long sA = 0, long long sB = 0, long long sC = 0) {
+                     int batch = 1, long long sA = 0, long long sB = 0, long long sC = 0, int srows = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.B = Bm; g.C = C; g.bias = bias; g.resid = resid; g.partial = w.gpart;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = sA; g.sB = sB; g.sC = sC; g.batch = batch; g.accumulate = accumulate; g.act = act; g.bf16 = bf16;
-    g.splitk = gemm_pick_splitk(M, N, K, batch, bf16);
+    g.splitk = sample_splitk(srows > 0 ? srows : M, N, K, bf16);  // srows: rows of ONE sample (M itself for batched GEMMs)
     HIPCHK(gemm_launch(g, s));
     return 0;
 }
@@ -577,7 +582,7 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     HIPCHK(layernorm_launch(c->dtype, x, tb->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps, w.ln0, M,
                             width, s));
     CHK(fnet_gemm(w, s, w.ln0, pf(c, packed, c->proj_w), w.X, M, hid, width, width, width, hid, pf(c, packed, c->proj_b),
-                  nullptr, 0, 0, bf));
+                  nullptr, 0, 0, bf, 1, 0, 0, 0, S));
     float* cur = w.X;
     float* other = w.Y;
     for (int i = 0; i < f.fnet_layers; ++i) {
@@ -591,18 +596,18 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
                       (long long)2 * hid * S, (long long)S * hid));
         HIPCHK(layernorm_launch(DT_F32, w.Z, nullptr, 1, pf(c, packed, L.ln1_w), pf(c, packed, L.ln1_b), eps, other, M, hid, s));
         // FFN; the second GEMM's split-K reduce also applies bias, residual and output.LayerNorm
-        CHK(fnet_gemm(w, s, other, pf(c, packed, L.w1), w.Hb, M, inter, hid, hid, hid, inter, pf(c, packed, L.b1), nullptr, 1, 0, bf));
+        CHK(fnet_gemm(w, s, other, pf(c, packed, L.w1), w.Hb, M, inter, hid, hid, hid, inter, pf(c, packed, L.b1), nullptr, 1, 0, bf, 1, 0, 0, 0, S));
         {
             GemmArgs g;
             memset(&g, 0, sizeof(g));
             g.A = w.Hb; g.B = pf(c, packed, L.w2); g.C = w.Z; g.bias = pf(c, packed, L.b2); g.resid = other; g.partial = w.gpart;
             g.M = M; g.N = hid; g.K = inter; g.lda = inter; g.ldb = inter; g.ldc = hid; g.batch = 1; g.bf16 = bf;
-            g.splitk = gemm_pick_splitk(M, hid, inter, 1, bf);
+            g.splitk = sample_splitk(S, hid, inter, bf);
             HIPCHK(gemm_ln_launch(g, pf(c, packed, L.ln2_w), pf(c, packed, L.ln2_b), eps, cur, s));
         }
     }
     CHK(fnet_gemm(w, s, cur, pf(c, packed, c->cout_w), w.O, M, width, hid, hid, hid, width, pf(c, packed, c->cout_b), nullptr,
-                  0, 0, bf));
+                  0, 0, bf, 1, 0, 0, 0, S));
     return 0;
 }
 
@@ -916,7 +921,7 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
                               {Mi, wd, h, 1, bf}, {wd, h, Mi, 1, bf}, {h, in, Mi, 1, bf}, {in, h, Mi, 1, bf}, {h, wd, Mi, 1, bf}};
         size_t mx = 0;
         for (auto& q : shp) {
-            const size_t n = (size_t)gemm_pick_splitk(q[0], q[1], q[2], q[3], q[4]) * q[3] * q[0] * q[1];
+            const size_t n = (size_t)kMaxSplitK * q[3] * q[0] * q[1];  // the split depends on the per-sample shape only; size for the cap
             if (n > mx) mx = n;
         }
         w->gpart = (float*)cv.take(mx * 4);
@@ -927,13 +932,13 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
 // GEMM helper over the training scratch (same call shape as fnet_gemm)
 static int tgemm(const TrainWs& w, hipStream_t s, const float* A, const float* Bm, float* C, int M, int N, int K, const float* bias,
                  const float* resid, int bf16, int batch = 1, long long sA = 0, long long sB = 0, long long sC = 0, int lda = -1,
-                 int ldb = -1) {
+                 int ldb = -1, int srows = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.B = Bm; g.C = C; g.bias = bias; g.resid = resid; g.partial = w.gpart;
     g.M = M; g.N = N; g.K = K; g.lda = lda < 0 ? K : lda; g.ldb = ldb < 0 ? K : ldb; g.ldc = N;
     g.sA = sA; g.sB = sB; g.sC = sC; g.batch = batch; g.bf16 = bf16;
-    g.splitk = gemm_pick_splitk(M, N, K, batch, bf16);
+    g.splitk = sample_splitk(srows > 0 ? srows : M, N, K, bf16);
     HIPCHK(gemm_launch(g, s));
     return 0;
 }
@@ -1076,7 +1081,7 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
     const int bf = dt == DT_BF16;
     HIPCHK(ln_train_launch(dt, cur, tables->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps_ln, tp.ln0, nullptr,
                            tp.ln0_stat, M, width, 0.f, seed, 0, s));
-    CHK(tgemm(w, s, tp.ln0, pf(c, packed, c->proj_w), tp.X0, M, hid, width, pf(c, packed, c->proj_b), nullptr, bf));
+    CHK(tgemm(w, s, tp.ln0, pf(c, packed, c->proj_w), tp.X0, M, hid, width, pf(c, packed, c->proj_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
     if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(tp.X0, tp.X0, (long long)M * hid, dropout_p, seed, 0, s));
     const float* xc = tp.X0;
     for (int i = 0; i < f.fnet_layers; ++i) {
@@ -1085,14 +1090,14 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
         CHK(fourier_mix(c, tables, w, xc, q.Z, B, S, s));
         HIPCHK(ln_train_launch(DT_F32, q.Z, nullptr, 1, pf(c, packed, Lw.ln1_w), pf(c, packed, Lw.ln1_b), eps_ln, q.Y1, nullptr,
                                q.zstat, M, hid, 0.f, seed, 0, s));
-        CHK(tgemm(w, s, q.Y1, pf(c, packed, Lw.w1), q.pre, M, inter, hid, pf(c, packed, Lw.b1), nullptr, bf));
+        CHK(tgemm(w, s, q.Y1, pf(c, packed, Lw.w1), q.pre, M, inter, hid, pf(c, packed, Lw.b1), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
         HIPCHK(gelu_launch(q.pre, nullptr, w.Hb, (long long)M * inter, 0, s));
-        CHK(tgemm(w, s, w.Hb, pf(c, packed, Lw.w2), w.dXa, M, hid, inter, pf(c, packed, Lw.b2), nullptr, bf));
+        CHK(tgemm(w, s, w.Hb, pf(c, packed, Lw.w2), w.dXa, M, hid, inter, pf(c, packed, Lw.b2), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
         HIPCHK(ln_train_launch(DT_F32, w.dXa, q.Y1, M, pf(c, packed, Lw.ln2_w), pf(c, packed, Lw.ln2_b), eps_ln, q.Xout, q.s,
                                q.sstat, M, hid, dropout_p, seed, (unsigned)(i + 1), s));
         xc = q.Xout;
     }
-    CHK(tgemm(w, s, xc, pf(c, packed, c->cout_w), w.O, M, width, hid, pf(c, packed, c->cout_b), nullptr, bf));
+    CHK(tgemm(w, s, xc, pf(c, packed, c->cout_w), w.O, M, width, hid, pf(c, packed, c->cout_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
     HIPCHK(resid_launch(dt, cur, w.O, 1, nullptr, nullptr, tp.up_in[L - 1], w.stats, B, S * c->Fr, CL, s));
     np = resid_nparts(dt, S * c->Fr, CL); cs = CL;
     for (int l = L - 1; l >= 0; --l) {

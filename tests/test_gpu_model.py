@@ -259,3 +259,22 @@ def test_fused_adam_and_clip_match_torch():
     with pytest.raises(NotImplementedError):
         O.get_optimizer(configs.dict2namespace(dict(optimizer="AdaBelief", lr=1e-3, weight_decay=0.0, beta=[0.9, 0.999], amsgrad=False,
                                                     eps=1e-8, clip_step=0.1)), ps_gpu)
+
+
+@pytest.mark.parametrize("tlen", [4096, 8192])
+def test_model_long_spectrograms_vs_oracle(audio_models, tlen):
+    """BASELINE configs 1 and 5 shapes (T = 8192 = sampling.t_size, T = 4096): fp32 HIP vs the CPU oracle for one sample,
+    bf16 vs fp32, and batch-independence at that length (S = T/32 = 128 / 256 tokens in the bottleneck)."""
+    cfg = configs.audio_config("torch.FloatTensor")
+    m32, m16 = audio_models[G.F32], audio_models[G.BF16]
+    sd = {k: v.detach().cpu() for k, v in m32.state_dict().items()}
+    x = synth.gaussian(f"long.x{tlen}", (2, 2, tlen, 256))
+    t = torch.tensor([640, 12])
+    with torch.no_grad():
+        want = ref_cpu.model_forward(sd, cfg, x[:1], t[:1])
+        y32 = m32(x.cuda(), t.cuda())
+        y16 = m16(x.cuda(), t.cuda())
+        solo = m32(x[1:2].cuda(), t[1:2].cuda())
+    G.check_close(y32[:1].cpu(), want, G.F32, f"T={tlen} fp32 vs oracle")
+    assert torch.equal(y32[1:2], solo)
+    G.check_close(y16.cpu(), y32.cpu(), G.BF16, f"T={tlen} bf16 vs fp32")
