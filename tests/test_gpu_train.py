@@ -17,7 +17,8 @@ DTS = [G.F32, G.BF16]
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("c,hw,b", [(32, (40, 72), 3), (64, (24, 40), 2), (96, (17, 33), 2), (128, (16, 24), 2),
-                                    (192, (9, 20), 1), (256, (20, 9), 2)])
+                                    (192, (9, 20), 1), (256, (20, 9), 2),
+                                    (32, (200, 48), 7)])  # 75 tiles per sample, 525 in all: workgroups walk 2 tiles and straddle samples
 def test_resblock_backward(dt, c, hw, b):
     p = f"rbt{c}."
     sd = _rb_sd(p, c)
@@ -184,11 +185,21 @@ def test_model_backward_ragged_shape_vs_oracle(mode):
     """Odd batch and a T whose bottleneck length is not a power of two (ragged conv tiles, ragged weight-gradient tiles,
     non-power-of-two DFT): loss and gradients against autograd through the CPU oracle."""
     dtype_str, dt = mode
+    _ragged_case(mode, (3, 2, 24, 32), [0, 999, 412])
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["f32", "bf16"])
+def test_model_backward_tall_shape_vs_oracle(mode):
+    """T = 256: several row chunks / strips in the edge-conv gradient kernels, multi-tile persistent conv workgroups."""
+    _ragged_case(mode, (2, 2, 256, 32), [77, 940])
+
+
+def _ragged_case(mode, shape, tt):
+    dtype_str, dt = mode
     cfg, m = _train_model("tiny", dtype_str, 5)
     _, alphas = make_schedule(cfg.diffusion)
-    shape = (3, 2, 24, 32)
     x0, e = synth.gaussian("ragged.x0", shape), synth.gaussian("ragged.e", shape)
-    t = torch.tensor([0, 999, 412])
+    t = torch.tensor(tt)
     loss = losses.noise_estimation_loss(m, x0.cuda(), t.cuda(), e.cuda(), alphas.cuda())
     loss.backward()
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
