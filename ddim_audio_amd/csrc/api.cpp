@@ -1133,6 +1133,8 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
     const ddimx_config& f = c->cfg;
     const int L = c->L, dt = c->dtype;
     if (B < 1 || T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("ddimx_unet_bwd: bad shape B=%d T=%d", B, T);
+    for (int l = 0; l < L; ++l) if (f.res[l] < 1) return fail("training needs at least one residual block per level");
+    if (dropout_p < 0.f || dropout_p >= 1.f) return fail("dropout probability %g out of [0, 1)", (double)dropout_p);
     TrainWs w;
     carve_train_ws(c, (char*)workspace, B, T, &w);
     if ((long long)w.total > workspace_bytes) return fail("training workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);

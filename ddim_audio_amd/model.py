@@ -226,6 +226,9 @@ class _UNetTrainFn(torch.autograd.Function):
         import ctypes
         lib = _lib.load()
         model, x = ctx.model, ctx.x
+        if ctx.tape is None:
+            raise RuntimeError("the tape of this forward was already consumed: backward through the same Model.forward twice "
+                               "(retain_graph) is not supported")
         b, t_len = x.size(0), x.size(2)
         total, layout = model._grad_layout(lib)
         with torch.cuda.device(x.device):
