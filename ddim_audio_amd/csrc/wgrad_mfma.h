@@ -68,6 +68,8 @@ struct WgCfg {
     static constexpr int LDS_RAW = SS_BYTES + DU_BYTES + HALO_BYTES;
     static constexpr int LDS_BYTES = LDS_RAW > RED_BYTES ? LDS_RAW : RED_BYTES;
     static constexpr int GRID_Y = (NBO / NCO) * (NBI / NCI);
+    // waves per SIMD the register allocator must leave room for
+    static constexpr int MINW = 1;
     static_assert(CI % 32 == 0 && CO % 32 == 0, "channel counts must be multiples of 32");
     static_assert(NBO % NCO == 0 && NBI % NCI == 0, "block grouping");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -75,7 +77,7 @@ struct WgCfg {
 };
 
 template <class C>
-__global__ void __launch_bounds__(C::NTHREADS) wgrad_mfma_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(C::NTHREADS, C::MINW) wgrad_mfma_kernel(const WgradArgs a) {
     typedef typename C::elem T;
     constexpr int ES = C::ES, EPB = C::EPB, ROW = C::ROW, PPB = C::PPB, S = C::S;
     constexpr int NP = EPB / 2;
@@ -112,11 +114,150 @@ __global__ void __launch_bounds__(C::NTHREADS) wgrad_mfma_kernel(const WgradArgs
     const int tr_col = (16 * (g16 & 1) + 4 * p4) * 2;     // byte offset inside the 64-byte row
     const int f_m = lane & 31, f_k = lane >> 5;
 
-    int cur_b = -1;
-#pragma unroll 1
-    for (int t = t_begin; t < t_end; ++t) {
+    // ---- staging.  bf16: the global loads of tile t+1 are issued right after tile t has been committed to LDS, so they
+    // are in flight while tile t is multiplied (register prefetch: NDU + NHA 16-byte pieces per thread).  fp32 (parity
+    // mode, twice the pieces) loads and commits a tile in place.
+    constexpr int NPC_DU = C::NCO * C::P * PPB, NPC_H = C::NCI * C::NPIX * PPB;
+    constexpr int NDU = (NPC_DU + C::NTHREADS - 1) / C::NTHREADS, NHA = (NPC_H + C::NTHREADS - 1) / C::NTHREADS;
+    // prefetch only where accumulators + prefetch registers leave two workgroups per CU (measured: it costs the 9-tap,
+    // 144-accumulator configurations their second workgroup and more than it gains)
+    constexpr bool PREF = ES == 2 && C::TPW * 16 + (NDU + NHA) * 4 <= 176;
+    static_assert(NHA <= 32, "halo validity mask");
+    uint4 pdu[PREF ? NDU : 1], pha[PREF ? NHA : 1];
+    unsigned pok = 0;
+    auto issue = [&](int t) __attribute__((always_inline)) {
         const int b = t / tiles_s, tt = t % tiles_s;
         const int y0 = (tt / a.tiles_x) * C::TH, x0 = (tt % a.tiles_x) * C::TW;
+        const __amdgpu_buffer_rsrc_t du_rsrc =
+            make_rsrc((const T*)a.du + (size_t)b * a.Hd * a.Wd * C::CO, (unsigned)((size_t)a.Hd * a.Wd * C::CO * ES));
+        const __amdgpu_buffer_rsrc_t a_rsrc =
+            make_rsrc((const T*)a.a + (size_t)b * a.Ha * a.Wa * C::CI, (unsigned)((size_t)a.Ha * a.Wa * C::CI * ES));
+#pragma unroll
+        for (int i = 0; i < NDU; ++i) {  // du tile: [blk][pixel][32 channels], zeros outside the image
+            const int idx = tid + i * C::NTHREADS;
+            const int j = idx % PPB, pix = (idx / PPB) % C::P, blk = idx / (PPB * C::P);
+            const int y = y0 + pix / C::TW, x = x0 + pix % C::TW;
+            const bool ok = idx < NPC_DU && y < a.Hd && x < a.Wd;
+            pdu[i] = buf_load16(du_rsrc, ok ? (unsigned)(((y * a.Wd + x) * C::CO + (cob0 + blk) * 32 + j * EPB) * ES) : kOOB);
+        }
+        pok = 0;
+#pragma unroll
+        for (int i = 0; i < NHA; ++i) {  // halo of `a`
+            const int idx = tid + i * C::NTHREADS;
+            const int j = idx % PPB, pix = (idx / PPB) % C::NPIX, blk = idx / (PPB * C::NPIX);
+            const int gy = y0 * S - 1 + pix / C::IW, gx = x0 * S - 1 + pix % C::IW;
+            const bool ok = idx < NPC_H && gy >= 0 && gy < a.Ha && gx >= 0 && gx < a.Wa;
+            pha[i] = buf_load16(a_rsrc, ok ? (unsigned)(((gy * a.Wa + gx) * C::CI + (cib0 + blk) * 32 + j * EPB) * ES) : kOOB);
+            pok |= ok ? 1u << i : 0u;
+        }
+        if constexpr (PREF) {  // keep the loads here: without this LLVM sinks them below the MFMA block, next to their use
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // registers -> LDS; the transform of `a` (padding is zero AFTER the transform) happens here
+    auto commit = [&](auto xf_tag) __attribute__((always_inline)) {
+        constexpr int XF = decltype(xf_tag)::value;
+#pragma unroll
+        for (int i = 0; i < NDU; ++i) {
+            const int idx = tid + i * C::NTHREADS;
+            if (idx < NPC_DU) *(uint4*)(du_l + (size_t)idx * 16) = pdu[i];  // idx order == LDS order
+        }
+#pragma unroll
+        for (int i = 0; i < NHA; ++i) {
+            const int idx = tid + i * C::NTHREADS;
+            if (idx >= NPC_H) continue;
+            uint4 w = pha[i];
+            if (XF != XF_NONE) {
+                const bool ok = (pok >> i) & 1u;
+                const int j = idx % PPB, blk = idx / (PPB * C::NPIX);
+                const float* sp = ss + (blk * 32 + j * EPB) * 2;
+                f32x2_t f[NP];
+                Pairs<T>::unpack(w, f);
+#pragma unroll
+                for (int e = 0; e < NP; ++e) {
+                    const f32x2_t sc = {sp[4 * e + 0], sp[4 * e + 2]}, sh = {sp[4 * e + 1], sp[4 * e + 3]};
+                    if (XF == XF_SILU_AFFINE) f[e] = silu2(f[e]);
+                    f[e] = fma2(f[e], sc, sh);
+                    if (XF == XF_AFFINE_SILU) f[e] = silu2(f[e]);
+                }
+                const uint4 tv = Pairs<T>::pack(f);
+                w.x = ok ? tv.x : 0u; w.y = ok ? tv.y : 0u; w.z = ok ? tv.z : 0u; w.w = ok ? tv.w : 0u;
+            }
+            *(uint4*)(ha_l + (size_t)idx * 16) = w;
+        }
+    };
+
+    // fp32: load + commit four pieces at a time (keeps the register footprint of the parity build small)
+    auto stage_in_place = [&](auto xf_tag, int t) __attribute__((always_inline)) {
+        constexpr int XF = decltype(xf_tag)::value;
+        const int b = t / tiles_s, tt = t % tiles_s;
+        const int y0 = (tt / a.tiles_x) * C::TH, x0 = (tt % a.tiles_x) * C::TW;
+        const __amdgpu_buffer_rsrc_t du_rsrc =
+            make_rsrc((const T*)a.du + (size_t)b * a.Hd * a.Wd * C::CO, (unsigned)((size_t)a.Hd * a.Wd * C::CO * ES));
+        const __amdgpu_buffer_rsrc_t a_rsrc =
+            make_rsrc((const T*)a.a + (size_t)b * a.Ha * a.Wa * C::CI, (unsigned)((size_t)a.Ha * a.Wa * C::CI * ES));
+#pragma unroll 1
+        for (int i0 = tid; i0 < NPC_DU; i0 += 4 * C::NTHREADS) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * C::NTHREADS;
+                const int j = idx % PPB, pix = (idx / PPB) % C::P, blk = idx / (PPB * C::P);
+                const int y = y0 + pix / C::TW, x = x0 + pix % C::TW;
+                const bool ok = idx < NPC_DU && y < a.Hd && x < a.Wd;
+                v[u] = buf_load16(du_rsrc, ok ? (unsigned)(((y * a.Wd + x) * C::CO + (cob0 + blk) * 32 + j * EPB) * ES) : kOOB);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * C::NTHREADS;
+                if (idx < NPC_DU) *(uint4*)(du_l + (size_t)idx * 16) = v[u];
+            }
+        }
+#pragma unroll 1
+        for (int i0 = tid; i0 < NPC_H; i0 += 4 * C::NTHREADS) {
+            uint4 v[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * C::NTHREADS;
+                const int j = idx % PPB, pix = (idx / PPB) % C::NPIX, blk = idx / (PPB * C::NPIX);
+                const int gy = y0 * S - 1 + pix / C::IW, gx = x0 * S - 1 + pix % C::IW;
+                ok[u] = idx < NPC_H && gy >= 0 && gy < a.Ha && gx >= 0 && gx < a.Wa;
+                v[u] = buf_load16(a_rsrc, ok[u] ? (unsigned)(((gy * a.Wa + gx) * C::CI + (cib0 + blk) * 32 + j * EPB) * ES) : kOOB);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * C::NTHREADS;
+                if (idx >= NPC_H) continue;
+                uint4 w = v[u];
+                if (XF != XF_NONE) {
+                    const int j = idx % PPB, blk = idx / (PPB * C::NPIX);
+                    const float* sp = ss + (blk * 32 + j * EPB) * 2;
+                    f32x2_t f[NP];
+                    Pairs<T>::unpack(w, f);
+#pragma unroll
+                    for (int e = 0; e < NP; ++e) {
+                        const f32x2_t sc = {sp[4 * e + 0], sp[4 * e + 2]}, sh = {sp[4 * e + 1], sp[4 * e + 3]};
+                        if (XF == XF_SILU_AFFINE) f[e] = silu2(f[e]);
+                        f[e] = fma2(f[e], sc, sh);
+                        if (XF == XF_AFFINE_SILU) f[e] = silu2(f[e]);
+                    }
+                    const uint4 tv = Pairs<T>::pack(f);
+                    w.x = ok[u] ? tv.x : 0u; w.y = ok[u] ? tv.y : 0u; w.z = ok[u] ? tv.z : 0u; w.w = ok[u] ? tv.w : 0u;
+                }
+                *(uint4*)(ha_l + (size_t)idx * 16) = w;
+            }
+        }
+    };
+
+    int cur_b = -1;
+    if constexpr (PREF) {
+        if (t_begin < t_end) issue(t_begin);
+    }
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const int b = t / tiles_s;
         __syncthreads();  // every wave is done reading the previous tile
         if (b != cur_b && a.xf != XF_NONE) {  // uniform
             for (int i = tid; i < C::NCI * 32; i += C::NTHREADS) {
@@ -126,76 +267,17 @@ __global__ void __launch_bounds__(C::NTHREADS) wgrad_mfma_kernel(const WgradArgs
             __syncthreads();
         }
         cur_b = b;
-        const __amdgpu_buffer_rsrc_t du_rsrc =
-            make_rsrc((const T*)a.du + (size_t)b * a.Hd * a.Wd * C::CO, (unsigned)((size_t)a.Hd * a.Wd * C::CO * ES));
-        const __amdgpu_buffer_rsrc_t a_rsrc =
-            make_rsrc((const T*)a.a + (size_t)b * a.Ha * a.Wa * C::CI, (unsigned)((size_t)a.Ha * a.Wa * C::CI * ES));
-        // ---- stage the du tile: [blk][pixel][32 channels], zeros outside the image ----
-        {
-            constexpr int NPC = C::NCO * C::P * PPB;
-#pragma unroll 1
-            for (int i0 = tid; i0 < NPC; i0 += 4 * C::NTHREADS) {
-                uint4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = i0 + u * C::NTHREADS;
-                    const int j = idx % PPB, pix = (idx / PPB) % C::P, blk = idx / (PPB * C::P);
-                    const int y = y0 + pix / C::TW, x = x0 + pix % C::TW;
-                    const bool ok = idx < NPC && y < a.Hd && x < a.Wd;
-                    v[u] = buf_load16(du_rsrc, ok ? (unsigned)(((y * a.Wd + x) * C::CO + (cob0 + blk) * 32 + j * EPB) * ES) : kOOB);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = i0 + u * C::NTHREADS;
-                    if (idx < NPC) *(uint4*)(du_l + (size_t)idx * 16) = v[u];  // idx order == LDS order
-                }
-            }
-        }
-        // ---- stage the halo of `a` with its transform; padding is zero AFTER the transform ----
-        auto stage_halo = [&](auto xf_tag) __attribute__((always_inline)) {
-            constexpr int XF = decltype(xf_tag)::value;
-            constexpr int NPC = C::NCI * C::NPIX * PPB;
-#pragma unroll 1
-            for (int i0 = tid; i0 < NPC; i0 += 4 * C::NTHREADS) {
-                uint4 v[4];
-                bool ok[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = i0 + u * C::NTHREADS;
-                    const int j = idx % PPB, pix = (idx / PPB) % C::NPIX, blk = idx / (PPB * C::NPIX);
-                    const int gy = y0 * S - 1 + pix / C::IW, gx = x0 * S - 1 + pix % C::IW;
-                    ok[u] = idx < NPC && gy >= 0 && gy < a.Ha && gx >= 0 && gx < a.Wa;
-                    v[u] = buf_load16(a_rsrc, ok[u] ? (unsigned)(((gy * a.Wa + gx) * C::CI + (cib0 + blk) * 32 + j * EPB) * ES) : kOOB);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = i0 + u * C::NTHREADS;
-                    if (idx >= NPC) continue;
-                    uint4 w = v[u];
-                    if (XF != XF_NONE) {
-                        const int j = idx % PPB, blk = idx / (PPB * C::NPIX);
-                        const float* sp = ss + (blk * 32 + j * EPB) * 2;
-                        f32x2_t f[NP];
-                        Pairs<T>::unpack(w, f);
-#pragma unroll
-                        for (int e = 0; e < NP; ++e) {
-                            const f32x2_t sc = {sp[4 * e + 0], sp[4 * e + 2]}, sh = {sp[4 * e + 1], sp[4 * e + 3]};
-                            if (XF == XF_SILU_AFFINE) f[e] = silu2(f[e]);
-                            f[e] = fma2(f[e], sc, sh);
-                            if (XF == XF_AFFINE_SILU) f[e] = silu2(f[e]);
-                        }
-                        const uint4 tv = Pairs<T>::pack(f);
-                        w.x = ok[u] ? tv.x : 0u; w.y = ok[u] ? tv.y : 0u; w.z = ok[u] ? tv.z : 0u; w.w = ok[u] ? tv.w : 0u;
-                    }
-                    *(uint4*)(ha_l + (size_t)idx * 16) = w;
-                }
-            }
+        auto stage = [&](auto xf_tag) __attribute__((always_inline)) {
+            if constexpr (PREF) commit(xf_tag); else stage_in_place(xf_tag, t);
         };
-        if (a.xf == XF_AFFINE_SILU) stage_halo(std::integral_constant<int, XF_AFFINE_SILU>());
-        else if (a.xf == XF_SILU_AFFINE) stage_halo(std::integral_constant<int, XF_SILU_AFFINE>());
-        else if (a.xf == XF_AFFINE) stage_halo(std::integral_constant<int, XF_AFFINE>());
-        else stage_halo(std::integral_constant<int, XF_NONE>());
+        if (a.xf == XF_AFFINE_SILU) stage(std::integral_constant<int, XF_AFFINE_SILU>());
+        else if (a.xf == XF_SILU_AFFINE) stage(std::integral_constant<int, XF_SILU_AFFINE>());
+        else if (a.xf == XF_AFFINE) stage(std::integral_constant<int, XF_AFFINE>());
+        else stage(std::integral_constant<int, XF_NONE>());
         __syncthreads();
+        if constexpr (PREF) {
+            if (t + 1 < t_end) issue(t + 1);
+        }
 
         // ---- MFMA: one k-step = one tile row of 16 pixels ----
         const char* du_b = du_l + co_i * (C::P * ROW);
