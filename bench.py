@@ -288,7 +288,7 @@ def main():
             out["roofline"].update(kernel=dom["kernel"], launch_us=dom["seconds"] * 1e6, alg_bytes_per_launch=dom["alg_bytes"],
                                    launches_per_fwd=dom["launches_per_fwd"])
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(T)
         if train_leg is not None:
             out["train_step"] = train_leg
