@@ -46,8 +46,12 @@ int conv_pick_variant(int dtype, int mode, int cin, int cout, int B, int Hv, int
     }
     if (conv_geometry(dtype, mode, cin, cout, 0, &g0) != hipSuccess) return 0;
     if (conv_geometry(dtype, mode, cin, cout, 1, &g1) != hipSuccess) return 0;
-    const long long wgs0 = (long long)B * ((Wv + g0.tw - 1) / g0.tw) * ((Hv + g0.th - 1) / g0.th) * g0.classes * (g0.nout / g0.nb);
-    return wgs0 < 200 ? 1 : 0;  // measured on MI355X: the large tile wins from ~256 workgroups up (one per CU)
+    // The choice depends on the SAMPLE's size only (never on B): a sample then runs through the same kernels, with the same
+    // statistics partition, alone or in any batch / on any number of GPUs -> bit-identical results.  The threshold is the
+    // one measured at the headline batch of 8 (the large tile wins from ~256 workgroups up, i.e. >= 25 tiles per sample).
+    (void)B;
+    const long long per_sample = (long long)((Wv + g0.tw - 1) / g0.tw) * ((Hv + g0.th - 1) / g0.th) * g0.classes * (g0.nout / g0.nb);
+    return per_sample * 8 < 200 ? 1 : 0;
 }
 }  // namespace ddimx
 
@@ -368,6 +372,8 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         // for bit) are the same alone, inside any batch, or on any number of GPUs.
         const int tiles_s = a.tiles_x * a.tiles_y;
         int wps = tiles_s < 128 ? tiles_s : 128;
+        if (tiles_s / 4 > wps) wps = tiles_s / 4;  // long spectrograms (T >= 2048): at most 4 tiles per workgroup, so that a
+                                                   // single sample still fills the 256 CUs
         if (const char* e = getenv("DDIMX_CONV_WPS")) { const int v = atoi(e); if (v > 0) wps = v < tiles_s ? v : tiles_s; }
         a.tiles_per_wg = cdiv(tiles_s, wps);
         a.wgs_per_sample = cdiv(tiles_s, a.tiles_per_wg);
