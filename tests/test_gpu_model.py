@@ -278,3 +278,17 @@ def test_model_long_spectrograms_vs_oracle(audio_models, tlen):
     G.check_close(y32[:1].cpu(), want, G.F32, f"T={tlen} fp32 vs oracle")
     assert torch.equal(y32[1:2], solo)
     G.check_close(y16.cpu(), y32.cpu(), G.BF16, f"T={tlen} bf16 vs fp32")
+
+
+@pytest.mark.parametrize("dt", [G.F32, G.BF16])
+def test_sample_result_does_not_depend_on_the_batch(audio_models, dt):
+    """The launch plan (tile variant, workgroups per sample, split-K) depends on the sample's size only: a sample's eps is
+    bit-identical alone and inside batches of 2, 5 and 9 -- hence on any number of GPUs when the batch is sharded."""
+    m = audio_models[dt]
+    x = synth.gaussian("inv.x", (9, 2, 1024, 256)).cuda()
+    t = (torch.arange(9) * 100 + 7).cuda()
+    with torch.no_grad():
+        solo = m(x[4:5], t[4:5])
+        for lo, hi in ((4, 6), (0, 5), (0, 9)):
+            y = m(x[lo:hi], t[lo:hi])
+            assert torch.equal(y[4 - lo:5 - lo], solo), f"batch {hi - lo}"
