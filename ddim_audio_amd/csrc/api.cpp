@@ -374,6 +374,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         int wps = tiles_s < 128 ? tiles_s : 128;
         if (tiles_s / 4 > wps) wps = tiles_s / 4;  // long spectrograms (T >= 2048): at most 4 tiles per workgroup, so that a
                                                    // single sample still fills the 256 CUs
+        if (q.cin >= 64 && tiles_s >= 512 && wps < 256) wps = 256;  // streamed-weight levels of long samples: 2 tiles per workgroup
         if (const char* e = getenv("DDIMX_CONV_WPS")) { const int v = atoi(e); if (v > 0) wps = v < tiles_s ? v : tiles_s; }
         a.tiles_per_wg = cdiv(tiles_s, wps);
         a.wgs_per_sample = cdiv(tiles_s, a.tiles_per_wg);
