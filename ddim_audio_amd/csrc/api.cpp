@@ -49,9 +49,10 @@ int conv_pick_variant(int dtype, int mode, int cin, int cout, int B, int Hv, int
     // The choice depends on the SAMPLE's size only (never on B): a sample then runs through the same kernels, with the same
     // statistics partition, alone or in any batch / on any number of GPUs -> bit-identical results.  The threshold is the
     // one measured at the headline batch of 8 (the large tile wins from ~256 workgroups up, i.e. >= 25 tiles per sample).
-    (void)B;
+    // (The training step passes its real batch: gradients depend on the whole batch anyway, and the large tile is faster
+    // once B x tiles fills the GPU.  B <= 0 selects the batch-independent rule.)
     const long long per_sample = (long long)((Wv + g0.tw - 1) / g0.tw) * ((Hv + g0.th - 1) / g0.th) * g0.classes * (g0.nout / g0.nb);
-    return per_sample * 8 < 200 ? 1 : 0;
+    return per_sample * (B > 0 ? B : 8) < 200 ? 1 : 0;
 }
 }  // namespace ddimx
 
@@ -343,13 +344,20 @@ struct ConvCall {
     const void* skip; void* out; float* stats;
     int B, Hin, Win;
     unsigned long long* stamps = nullptr;
+    bool batch_plan = false;  // training: choose the tile variant from the real batch (inference: sample size only)
 };
 
+// set for the duration of the whole-network training calls (see ConvCall::batch_plan)
+static thread_local bool g_batch_plan = false;
+struct BatchPlanScope {
+    BatchPlanScope() { g_batch_plan = true; }
+    ~BatchPlanScope() { g_batch_plan = false; }
+};
 // launches one fused conv; returns the stats slab geometry (nparts, Cs) it produced
 static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     ConvGeom g;
     const int hv = q.mode == DOWN4 ? q.Hin / 2 : q.Hin, wv = q.mode == DOWN4 ? q.Win / 2 : q.Win;
-    const int var = conv_pick_variant(q.dtype, q.mode, q.cin, q.cout, q.B, hv, wv);
+    const int var = conv_pick_variant(q.dtype, q.mode, q.cin, q.cout, (q.batch_plan || g_batch_plan) ? q.B : 0, hv, wv);
     if (conv_geometry(q.dtype, q.mode, q.cin, q.cout, var, &g) != hipSuccess)
         return fail("conv %d->%d mode %d dtype %d: no kernel", q.cin, q.cout, q.mode, q.dtype);
     ConvArgs a;
@@ -1048,6 +1056,7 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
     if (T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("T=%d must be a positive multiple of %d", T, 1 << (L - 1));
     if (dropout_p < 0.f || dropout_p >= 1.f) return fail("dropout probability %g out of [0, 1)", (double)dropout_p);
     for (int l = 0; l < L; ++l) if (f.res[l] < 1) return fail("training needs at least one residual block per level");
+    BatchPlanScope plan_scope;
     TrainWs w;
     carve_train_ws(c, (char*)workspace, B, T, &w);
     if ((long long)w.total > workspace_bytes) return fail("training workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
@@ -1142,6 +1151,7 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
     if (B < 1 || T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("ddimx_unet_bwd: bad shape B=%d T=%d", B, T);
     for (int l = 0; l < L; ++l) if (f.res[l] < 1) return fail("training needs at least one residual block per level");
     if (dropout_p < 0.f || dropout_p >= 1.f) return fail("dropout probability %g out of [0, 1)", (double)dropout_p);
+    BatchPlanScope plan_scope;
     TrainWs w;
     carve_train_ws(c, (char*)workspace, B, T, &w);
     if ((long long)w.total > workspace_bytes) return fail("training workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
