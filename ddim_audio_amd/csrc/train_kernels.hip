@@ -677,8 +677,55 @@ __global__ void __launch_bounds__(256) conv_out_bwd_data_kernel(const float* __r
         *(uint4*)(ds + ((size_t)b * H * W + pix) * C0 + c0) = Piece<T>::pack(acc);
     }
 }
+// Fast path (C0 = 32, cout = 2): every thread keeps the 9 x 2 x EPB weights of its channel piece in registers and walks
+// pixels; the 18 d_eps values of a pixel are shared by the piece lanes (same address: one transaction).
+template <typename T>
+__global__ void __launch_bounds__(256) conv_out_bwd_data_reg_kernel(const float* __restrict__ de, const float* __restrict__ w,
+                                                                    T* __restrict__ ds, int H, int W) {
+    constexpr int C0 = 32, COUT = 2, EPB = Piece<T>::N, PPB = C0 / EPB, PIX = 256 / PPB;
+    const int j = threadIdx.x % PPB, pl = threadIdx.x / PPB, b = blockIdx.y;
+    float wr[9 * COUT][EPB];
+#pragma unroll
+    for (int ko = 0; ko < 9 * COUT; ++ko)
+#pragma unroll
+        for (int e = 0; e < EPB; ++e) wr[ko][e] = w[ko * C0 + j * EPB + e];
+    const long long HW = (long long)H * W;
+    const float* d0 = de + (size_t)b * COUT * HW;
+    for (long long pix = (long long)blockIdx.x * PIX + pl; pix < HW; pix += (long long)gridDim.x * PIX) {
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        float dv[9 * COUT];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y - k / 3 + 1, xx = x - k % 3 + 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t off = ok ? (size_t)yy * W + xx : 0;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const float v = d0[(size_t)o * HW + off];
+                dv[k * COUT + o] = ok ? v : 0.f;
+            }
+        }
+        float acc[EPB];
+#pragma unroll
+        for (int e = 0; e < EPB; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ko = 0; ko < 9 * COUT; ++ko)
+#pragma unroll
+            for (int e = 0; e < EPB; ++e) acc[e] = fmaf(dv[ko], wr[ko][e], acc[e]);
+        *(uint4*)(ds + ((size_t)b * HW + pix) * C0 + j * EPB) = Piece<T>::pack(acc);
+    }
+}
 hipError_t conv_out_bwd_data_launch(int dtype, const float* d_eps, const float* w, void* ds, int B, int C0, int cout, int H,
                                     int W, hipStream_t s) {
+    if (C0 == 32 && cout == 2) {
+        const long long HW = (long long)H * W;
+        const int pixb = dtype == DT_BF16 ? 64 : 32;
+        const long long want = (HW + pixb * 8 - 1) / (pixb * 8);  // ~8 pixels per thread
+        dim3 grid((unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want)), B);
+        if (dtype == DT_BF16) hipLaunchKernelGGL(conv_out_bwd_data_reg_kernel<__bf16>, grid, dim3(256), 0, s, d_eps, w, (__bf16*)ds, H, W);
+        else hipLaunchKernelGGL(conv_out_bwd_data_reg_kernel<float>, grid, dim3(256), 0, s, d_eps, w, (float*)ds, H, W);
+        return hipGetLastError();
+    }
     const int epb = dtype == DT_BF16 ? 8 : 4;
     if (C0 % epb) return hipErrorInvalidValue;
     const long long pieces = (long long)H * W * (C0 / epb);
