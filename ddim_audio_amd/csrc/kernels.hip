@@ -85,7 +85,11 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
                                                            const float* __restrict__ bias, T* __restrict__ out,
                                                            float* __restrict__ stats, int H, int W) {
     constexpr int EPB = Piece<T>::N;
+    constexpr int ROWB = C0 * (int)sizeof(T), PCS = ROWB / 16;  // bytes / 16-byte pieces per pixel
     __shared__ float red[4][C0 * 2];
+    // per-wave staging tile: a lane computes one pixel (ROWB contiguous bytes), but a store instruction should write
+    // contiguous memory across the lanes -> pieces go through LDS (row stride ROWB + 16 keeps the b128 accesses conflict-free)
+    __shared__ __attribute__((aligned(16))) char otile[4][64 * (ROWB + 16)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, part = blockIdx.x;
     const int HW = H * W;
@@ -94,8 +98,10 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
 #pragma unroll
     for (int c = 0; c < C0; ++c) s[c] = q[c] = 0.f;
     for (int it = 0; it < kInPixPerBlock / 256; ++it) {
-        const int pix = part * kInPixPerBlock + it * 256 + tid;
-        if (pix >= HW) break;
+        const int pix0 = part * kInPixPerBlock + it * 256 + wave * 64;  // first pixel of this wave (uniform)
+        if (pix0 >= HW) break;
+        const bool valid = pix0 + lane < HW;  // ragged last wave: idle lanes still help with the stores below
+        const int pix = valid ? pix0 + lane : HW - 1;
         const int py = pix / W, px = pix % W;
         float v[CIN * 9];
 #pragma unroll
@@ -105,7 +111,7 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
                 const int gy = py + k / 3 - 1, gx = px + k % 3 - 1;
                 v[ci * 9 + k] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)ci * HW + (size_t)gy * W + gx] : 0.f;
             }
-        T* op = out + ((size_t)b * HW + pix) * C0;
+        char* my = otile[wave] + lane * (ROWB + 16);
 #pragma unroll
         for (int c0 = 0; c0 < C0; c0 += EPB) {
             float acc[EPB];
@@ -118,10 +124,27 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
             }
             const uint4 pv = Piece<T>::pack(acc);
             Piece<T>::unpack(pv, acc);
-            *(uint4*)(op + c0) = pv;
+            *(uint4*)(my + (c0 / EPB) * 16) = pv;
+            if (valid) {
 #pragma unroll
-            for (int j = 0; j < EPB; ++j) { s[c0 + j] += acc[j]; q[c0 + j] = fmaf(acc[j], acc[j], q[c0 + j]); }
+                for (int j = 0; j < EPB; ++j) { s[c0 + j] += acc[j]; q[c0 + j] = fmaf(acc[j], acc[j], q[c0 + j]); }
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the wave's 64 pixels are consecutive in memory: store them as PCS instructions of 1 KiB contiguous each
+        char* obase = (char*)(out + ((size_t)b * HW + pix0) * C0);
+        const int npix = HW - pix0 < 64 ? HW - pix0 : 64;
+#pragma unroll
+        for (int k = 0; k < PCS; ++k) {
+            const int idx = k * 64 + lane;           // piece index inside the wave's tile
+            const int p = idx / PCS, pc = idx % PCS;
+            const uint4 vv = *(const uint4*)(otile[wave] + p * (ROWB + 16) + pc * 16);
+            if (p < npix) *(uint4*)(obase + (size_t)idx * 16) = vv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     if (stats) {
 #pragma unroll
