@@ -115,6 +115,9 @@ class FusedAdam(optim.Optimizer):
                                                 _lib.ptr(tb.sizes), _lib.ptr(tb.bt), _lib.ptr(tb.bo), tb.nblk, None, float(group["lr"]),
                                                 float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                                                 int(steps.pop()), int(group["decoupled"]), _lib.stream()))
+            # the kernel wrote through raw pointers: bump the version counters so that caches keyed on them (the model's
+            # packed weights) notice, exactly as an in-place torch op would
+            torch.autograd.graph.increment_version(ps)
         return loss
 
 

@@ -238,7 +238,9 @@ def test_fused_adam_and_clip_match_torch():
             assert abs(float(n_ours) - float(n_ref)) <= 2e-6 * float(n_ref)
             for pc, pg in zip(ps_cpu, ps_gpu):
                 assert torch.allclose(pg.grad.cpu(), pc.grad, rtol=2e-6, atol=1e-9)
+            versions = [p._version for p in ps_gpu]
             ref.step(); ours.step(); sch_ref.step(); sch.step()
+            assert all(p._version > v for p, v in zip(ps_gpu, versions)), "fused step must bump the version counters"
             for pc, pg in zip(ps_cpu, ps_gpu):
                 assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=3e-6, atol=3e-7), (decoupled, it)
     # AdaBelief (the reference's default group): published algorithm, parity unpinned (source absent upstream)
