@@ -95,6 +95,59 @@ def test_model_backward_golden(golden, mode, name, shape, seed):
     assert abs(got_total ** 0.5 - total) <= (1e-4 if dt == G.F32 else 2e-2) * total
 
 
+def test_reference_runner_sequence_golden(golden):
+    """The literal statement sequence of the reference's Diffusion.train_step (runners/diffusion.py:130-173) over the drop-in
+    symbols -- loss_registry, zero_grad, backward, torch.nn.utils.clip_grad_norm_, optimizer / scheduler steps, EMAHelper --
+    reproduces the reference's first optimisation step."""
+    from ddim_audio_amd import train
+    from ddim_audio_amd.dropin.functions import get_optimizer, get_scheduler
+    from ddim_audio_amd.dropin.functions.losses import loss_registry
+    from ddim_audio_amd.dropin.models.ema import EMAHelper
+    g = golden("train")
+    cfg, model = _train_model("tiny", "torch.cuda.FloatTensor", 3)
+    optimizers, schedulers = {}, {}
+    for name, p_opt in train.classify_group(cfg.optimization.optimizer, model).items():
+        optimizers[name] = get_optimizer(p_opt.config, p_opt.params)
+        schedulers[name] = get_scheduler(p_opt.config, optimizers[name])
+    grad_group = train.classify_group(cfg.optimization.grad_norm, model)
+    ema_helper = EMAHelper(mu=cfg.model.ema_rate)
+    ema_helper.register(model)
+    _, alphas = make_schedule(cfg.diffusion)
+    x = synth.gaussian("train.tiny.x0", (2, 2, 16, 32)).cuda()
+    e = synth.gaussian("train.tiny.e", (2, 2, 16, 32)).cuda()
+    t = torch.from_numpy(g["tiny_t"]).cuda()
+    model.train()
+    loss = loss_registry[cfg.model.type](model, x, t, e, alphas.cuda())
+    assert abs(loss.item() - float(g["step0_loss"])) < 1e-4 * float(g["step0_loss"])
+    for optimizer in optimizers.values():
+        optimizer.zero_grad()
+    loss.backward()
+    for name, p_opt in grad_group.items():
+        norm = torch.nn.utils.clip_grad_norm_(p_opt.params, p_opt.config.grad_clip)
+        assert abs(float(norm) - float(g[f"step0_norm_{name}"])) < 1e-3 * float(norm)
+    for optimizer in optimizers.values():
+        optimizer.step()
+    for scheduler in schedulers.values():
+        scheduler.step()
+    ema_helper.update(model)
+    states = [model.state_dict(), optimizer.state_dict(), 0, 1, ema_helper.state_dict()]
+    assert len(states[0]) == 1 + len(list(model.parameters())) and "state" in states[1]
+    for n, p in model.named_parameters():
+        stride = max(1, p.numel() // 64)
+        ref = g[f"step0_p::{n}"]
+        lr = 5e-4 if n.startswith("transformer.") else 3e-4
+        assert np.abs(p.detach().cpu().reshape(-1)[::stride][:64].numpy() - ref).max() <= 0.02 * lr + 1e-6 * np.abs(ref).max(), n
+        sh = ema_helper.shadow[n].cpu().reshape(-1)[::stride][:64].numpy()
+        assert np.abs(sh - g[f"step0_ema::{n}"]).max() <= 1e-5 * np.abs(ref).max() + 1e-7, n
+    # the next forward must see the updated weights without any explicit invalidation
+    with torch.no_grad():
+        y1 = model.eval()(x, t)
+        fresh = D.Model(cfg)
+        fresh.load_state_dict(model.state_dict())
+        y2 = fresh.eval()(x, t)
+    assert torch.equal(y1, y2)
+
+
 def test_training_steps_golden(golden):
     """Two full optimisation steps (loss, backward, clip, fused Adam/AdamW, LambdaLR, EMA) against the reference's own
     train_step tail (fp32 mode).  Adam divides by sqrt(v) + eps, which amplifies gradient noise where |g| ~ eps; the gate
