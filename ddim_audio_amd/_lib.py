@@ -70,6 +70,8 @@ _SIGS = {
     "ddimx_upsample_add_fwd": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_int, c_void_p]),
     "ddimx_temb_fwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "ddimx_fnet_mix_supported": (c_int, [c_int, c_int]),
+    "ddimx_fnet_mix": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_step_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ddimx_step_begin_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "ddimx_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),

@@ -604,11 +604,15 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
         const ddimx_ctx::FL& L = c->fl[i];
         // Ut[b] = D_H * X[b]^T -> [2*hid][S]; D_H rows interleaved (2k: cos_k, 2k+1: sin_k), so that row pair k of
         // Ut[b] is one contiguous K-vector [cos-part(S) | sin-part(S)] for the sequence transform
+        if (fnet_mix_supported(S, hid) && !(getenv("DDIMX_FNET_MIX") && atoi(getenv("DDIMX_FNET_MIX")) == 0)) {
+            HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, cur, w.Z, B, S, hid, s));
+        } else {
         CHK(fnet_gemm(w, s, tb->dft_hidden, cur, w.Ut, 2 * hid, S, hid, hid, hid, S, nullptr, nullptr, 0, 0, 0, B, 0,
                       (long long)S * hid, (long long)2 * hid * S));
         // Z[b] = [C_S | -S_S] * Ut[b]^T + X[b]   (Re(FFT2) + residual) in one GEMM with K = 2S
         CHK(fnet_gemm(w, s, tb->dft_seq, w.Ut, w.Z, S, hid, 2 * S, 2 * S, 2 * S, hid, nullptr, cur, 0, 0, 0, B, 0,
                       (long long)2 * hid * S, (long long)S * hid));
+        }
         HIPCHK(layernorm_launch(DT_F32, w.Z, nullptr, 1, pf(c, packed, L.ln1_w), pf(c, packed, L.ln1_b), eps, other, M, hid, s));
         // FFN; the second GEMM's split-K reduce also applies bias, residual and output.LayerNorm
         CHK(fnet_gemm(w, s, other, pf(c, packed, L.w1), w.Hb, M, inter, hid, hid, hid, inter, pf(c, packed, L.b1), nullptr, 1, 0, bf, 1, 0, 0, 0, S));
@@ -961,6 +965,10 @@ static int tgemm(const TrainWs& w, hipStream_t s, const float* A, const float* B
 static int fourier_mix(const ddimx_ctx* c, const ddimx_tables* tb, const TrainWs& w, const float* X, float* Z, int B, int S,
                        hipStream_t s) {
     const int hid = c->cfg.fnet_hidden;
+    if (fnet_mix_supported(S, hid) && !(getenv("DDIMX_FNET_MIX") && atoi(getenv("DDIMX_FNET_MIX")) == 0)) {
+        HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, X, Z, B, S, hid, s));
+        return 0;
+    }
     CHK(tgemm(w, s, tb->dft_hidden, X, w.Ut, 2 * hid, S, hid, nullptr, nullptr, 0, B, 0, (long long)S * hid, (long long)2 * hid * S));
     CHK(tgemm(w, s, tb->dft_seq, w.Ut, Z, S, hid, 2 * S, nullptr, X, 0, B, 0, (long long)2 * hid * S, (long long)S * hid));
     return 0;
@@ -1460,6 +1468,30 @@ int ddimx_temb_fwd(const float* te, const int64_t* t, const float* w0, const flo
                    const float* w2, const float* b2, float* h1, float* h2, float* out, int B, int pos_ch, int emb_ch, int E,
                    void* stream) {
     return run_temb(te, t, w0, b0, w1, b1, w2, b2, h1, h2, out, B, pos_ch, emb_ch, E, (hipStream_t)stream);
+}
+
+// Z[b] = Re(FFT2(X[b])) + X[b] over [B][S][hid] fp32 token matrices (the FNet mixing + residual; also its own backward).
+// fused = 1: the single-launch kernel (needs ddimx_fnet_mix_supported); 0: two GEMMs through `ut` ([B][2*hid][S]) and
+// `partial` (split-K scratch, 8*B*2*hid*S floats).
+int ddimx_fnet_mix_supported(int S, int hid) { return fnet_mix_supported(S, hid) ? 1 : 0; }
+int ddimx_fnet_mix(const float* dft_hidden, const float* dft_seq, const float* x, float* z, float* ut, float* partial, int B, int S,
+                   int hid, int fused, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (fused) {
+        if (!fnet_mix_supported(S, hid)) return fail("ddimx_fnet_mix: S=%d hid=%d not supported by the fused kernel", S, hid);
+        HIPCHK(fnet_mix_launch(dft_hidden, dft_seq, x, z, B, S, hid, s));
+        return 0;
+    }
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dft_hidden; g.B = x; g.C = ut; g.partial = partial; g.M = 2 * hid; g.N = S; g.K = hid; g.lda = hid; g.ldb = hid; g.ldc = S;
+    g.sB = (long long)S * hid; g.sC = (long long)2 * hid * S; g.batch = B; g.splitk = sample_splitk(2 * hid, S, hid, 0);
+    HIPCHK(gemm_launch(g, s));
+    memset(&g, 0, sizeof(g));
+    g.A = dft_seq; g.B = ut; g.C = z; g.resid = x; g.partial = partial; g.M = S; g.N = hid; g.K = 2 * S; g.lda = 2 * S; g.ldb = 2 * S;
+    g.ldc = hid; g.sB = (long long)2 * hid * S; g.sC = (long long)S * hid; g.batch = B; g.splitk = sample_splitk(S, hid, 2 * S, 0);
+    HIPCHK(gemm_launch(g, s));
+    return 0;
 }
 
 int ddimx_step_begin(const float* coef, const int* step, int64_t* t, int B, void* stream) {

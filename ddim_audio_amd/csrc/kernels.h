@@ -58,6 +58,10 @@ struct GemmArgs {
 };
 hipError_t gemm_launch(GemmArgs g, hipStream_t s);
 int gemm_pick_splitk(int M, int N, int K, int batch, int bf16);
+// Z[b] = Re(FFT2(X[b])) + X[b] in one launch (gemm.hip); dft_hidden [2hid][hid] interleaved cos/sin rows, dft_seq [S][2S]
+bool fnet_mix_supported(int S, int hid);
+hipError_t fnet_mix_launch(const float* dft_hidden, const float* dft_seq, const float* X, float* Z, int B, int S, int hid,
+                           hipStream_t s);
 // out = LayerNorm(A*B^T + bias + resid) * gamma + beta (rows of N <= 2048), GEMM via the partial workspace
 hipError_t gemm_ln_launch(GemmArgs g, const float* gamma, const float* beta, float eps, float* out, hipStream_t s);
 

@@ -190,6 +190,13 @@ int ddimx_temb_fwd(const float* te, const int64_t* t, const float* w0, const flo
 /* coef [n_iter][6] fp32 rows (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1); step: device int counter.
  * step_begin fills t[B] with the current timestep; ddim_update performs lines :27 and :41-43 in one pass,
  * writing the x0 prediction to x0 and x_{t-1} in place; step_end advances the counter. */
+/* FNet Fourier mixing with its residual, transformers modeling_fnet.py:138-166 (`fftn(x, dim=(1, 2)).real`) + :182:
+ * z[b] = Re(FFT2(x[b])) + x[b] over fp32 [B][S][hid]; dft_hidden / dft_seq as in ddimx_tables.  fused = 1: one launch
+ * (when ddimx_fnet_mix_supported(S, hid)); fused = 0: two exact-fp32 GEMMs through ut [B][2*hid][S] and the split-K
+ * scratch partial [8*B*2*hid*S floats].  The operator is symmetric, so it is also its own backward. */
+int ddimx_fnet_mix_supported(int S, int hid);
+int ddimx_fnet_mix(const float* dft_hidden, const float* dft_seq, const float* x, float* z, float* ut, float* partial, int B,
+                   int S, int hid, int fused, void* stream);
 int ddimx_step_begin(const float* coef, const int* step, int64_t* t, int B, void* stream);
 /* as ddimx_step_begin for coefficient tables with another row stride (ddpm_steps: 7) */
 int ddimx_step_begin_ex(const float* coef, int row_stride, const int* step, int64_t* t, int B, void* stream);

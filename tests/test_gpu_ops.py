@@ -115,3 +115,30 @@ def test_ddim_update_matches_oracle_bitwise(golden):
         assert torch.allclose(x0.cpu(), r0, rtol=3e-7, atol=1e-7), k
         assert torch.allclose(xt.cpu(), ref, rtol=3e-7, atol=1e-7), k
     assert int(step.item()) == len(seq)
+
+
+@pytest.mark.parametrize("b,s_len,hid", [(3, 32, 512), (2, 16, 512), (1, 8, 256), (2, 24, 128)])
+def test_fnet_fourier_mixing(b, s_len, hid):
+    """Re(FFT2(x)) + x: the single-launch kernel and the two-GEMM path against torch.fft on the CPU (fp32, exact MFMA)."""
+    import numpy as np
+    from ddim_audio_amd.model import _dft_tables
+    lib = _lib.load()
+    x = synth.gaussian(f"mix.x{s_len}.{hid}", (b, s_len, hid))
+    want = torch.fft.fftn(x.double(), dim=(1, 2)).real.float() + x
+    ch, sh = _dft_tables(hid)
+    cs, ss = _dft_tables(s_len)
+    dh = torch.from_numpy(np.stack([ch, sh], axis=1).reshape(2 * hid, hid)).cuda()
+    ds = torch.from_numpy(np.concatenate([cs, -ss], axis=1)).contiguous().cuda()
+    xg = x.cuda()
+    ut = torch.empty(b * 2 * hid * s_len, device="cuda")
+    part = torch.empty(8 * b * 2 * hid * s_len, device="cuda")
+    outs = {}
+    for fused in (0, 1):
+        if fused and not lib.ddimx_fnet_mix_supported(s_len, hid):
+            continue
+        z = torch.full_like(xg, float("nan"))
+        _lib.check(lib.ddimx_fnet_mix(_lib.ptr(dh), _lib.ptr(ds), _lib.ptr(xg), _lib.ptr(z), _lib.ptr(ut), _lib.ptr(part), b, s_len, hid,
+                                      fused, _lib.stream()))
+        outs[fused] = z.cpu()
+        G.check_close(outs[fused], want, G.F32, f"fourier mixing fused={fused}")
+    assert 1 in outs or not lib.ddimx_fnet_mix_supported(s_len, hid)
