@@ -288,42 +288,47 @@ __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__
     for (int i = tid; i < S * 2 * S; i += 256) dsl[i] = dft_seq[i];
 
     constexpr int F4 = MIX_BK / 4;                              // float4 per row per chunk
-    float4 ra[64 * F4 / 256], rb[32 * F4 / 256];
-    auto load = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 64 * F4 / 256; ++i) {
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
-            ra[i] = *(const float4*)(A + (size_t)row * hid + k0 + kq);
-        }
-#pragma unroll
-        for (int i = 0; i < 32 * F4 / 256; ++i) {
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
-            rb[i] = row < S ? *(const float4*)(Xb + (size_t)row * hid + k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store = [&](int buf) __attribute__((always_inline)) {
-        char* pa = sAB + buf * MixSmem::STAGE;
-        char* pb = pa + MixSmem::A_BYTES;
-#pragma unroll
-        for (int i = 0; i < 64 * F4 / 256; ++i) {
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
-            *(float4*)(pa + row * MIX_ROWB + kq * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 32 * F4 / 256; ++i) {
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
-            *(float4*)(pb + row * MIX_ROWB + kq * 4) = rb[i];
-        }
-    };
+    constexpr int NA = 64 * F4 / 256, NB = 32 * F4 / 256;
+    // two chunks of loads are kept in flight in registers (the K loop is latency-bound): set 1 = chunk kc+1, set 2 = kc+2
+    f32x4_t ra1[NA], rb1[NB], ra2[NA], rb2[NB];  // native vectors: HIP's float4 struct arrays were left in scratch memory
+#define DDIMX_MIX_LOAD(RA, RB, K0)                                                                                     \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                               \
+            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
+            RA[i] = *(const f32x4_t*)(A + (size_t)row * hid + (K0) + kq);                                               \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
+            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
+            RB[i] = row < S ? *(const f32x4_t*)(Xb + (size_t)row * hid + (K0) + kq) : (f32x4_t)(0.f);                  \
+        }                                                                                                              \
+    } while (0)
+#define DDIMX_MIX_STORE(BUF, RA, RB)                                                                                   \
+    do {                                                                                                               \
+        char* pa_ = sAB + (BUF) * MixSmem::STAGE;                                                                      \
+        char* pb_ = pa_ + MixSmem::A_BYTES;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                               \
+            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
+            *(f32x4_t*)(pa_ + row * MIX_ROWB + kq * 4) = RA[i];                                                         \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
+            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
+            *(f32x4_t*)(pb_ + row * MIX_ROWB + kq * 4) = RB[i];                                                         \
+        }                                                                                                              \
+    } while (0)
     f32x16_t acc0;  // this wave's 32 Ut rows x 32 token columns, over its half of every k chunk
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
     const int nk = hid / MIX_BK;
-    load(0);
-    store(0);
+    DDIMX_MIX_LOAD(ra1, rb1, 0);
+    if (nk > 1) DDIMX_MIX_LOAD(ra2, rb2, MIX_BK);
+    DDIMX_MIX_STORE(0, ra1, rb1);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra1[i] = ra2[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb1[i] = rb2[i];
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 1 < nk) load((kc + 1) * MIX_BK);
+        if (kc + 2 < nk) DDIMX_MIX_LOAD(ra2, rb2, (kc + 2) * MIX_BK);
         const char* pa = sAB + (kc & 1) * MixSmem::STAGE + (wm * 32 + l31) * MIX_ROWB + h * 16;
         const char* pb = sAB + (kc & 1) * MixSmem::STAGE + MixSmem::A_BYTES + l31 * MIX_ROWB + h * 16;
 #pragma unroll
@@ -336,7 +341,13 @@ __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b0.z), acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b0.w), acc0, 0, 0, 0);
         }
-        if (kc + 1 < nk) store((kc + 1) & 1);
+        if (kc + 1 < nk) {
+            DDIMX_MIX_STORE((kc + 1) & 1, ra1, rb1);  // chunk kc+1 was requested an iteration ago
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra1[i] = ra2[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb1[i] = rb2[i];
+        }
         __syncthreads();
     }
     // Ut -> LDS, de-interleaved: utc[j][s] = Ut[2j][s] (cos rows), uts[j][s] = Ut[2j+1][s]; row stride 65 floats.
@@ -368,6 +379,8 @@ __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__
         Z[o] = a + X[o];
     }
 }
+#undef DDIMX_MIX_LOAD
+#undef DDIMX_MIX_STORE
 bool fnet_mix_supported(int S, int hid) { return S >= 8 && S <= 32 && S % 8 == 0 && hid % MIX_BK == 0 && hid % 32 == 0; }
 hipError_t fnet_mix_launch(const float* dft_hidden, const float* dft_seq, const float* X, float* Z, int B, int S, int hid,
                            hipStream_t s) {
