@@ -36,10 +36,13 @@
     X(__bf16, 128, 192, 192, DOWN4, 8, 8, 2, 2, 32, 1, 0, 0) \
     X(__bf16, 192, 256, 256, DOWN4, 4, 8, 1, 4, 32, 1, 0, 0) \
     X(__bf16, 256, 384, 384, UP4, 8, 8, 2, 2, 32, 1, 0, 0)   \
-    X(__bf16, 192, 256, 256, UP4, 8, 8, 2, 2, 64, 1, 0, 0)   \
+    X(__bf16, 192, 256, 128, UP4, 8, 16, 4, 2, 96, 1, 0, 0)  \
     X(__bf16, 128, 192, 192, UP4, 8, 8, 2, 2, 64, 1, 0, 0)   \
     X(__bf16, 96, 128, 128, UP4, 8, 16, 4, 1, 96, 1, 0, 0)   \
-    X(__bf16, 64, 64, 64, UP4, 8, 32, 8, 1, 64, 1, 0, 0)
+    X(__bf16, 64, 64, 64, UP4, 8, 32, 8, 1, 64, 1, 0, 0)     \
+    X(__bf16, 192, 256, 128, DOWN4, 4, 8, 1, 4, 96, 1, 1, 0)  \
+    X(__bf16, 128, 192, 96, DOWN4, 4, 8, 1, 3, 128, 1, 1, 0)  \
+    X(__bf16, 256, 384, 128, UP4, 8, 8, 2, 2, 128, 1, 1, 0)
 
 #define DDIMX_CONV3_F32(X)                          \
     X(float, 32, 32, 32, CONV3, 8, 32, 8, 1, 32, 9, 0, 0) \
