@@ -12,12 +12,12 @@
     X(__bf16, 32, 32, 32, CONV3, 16, 32, 4, 1, 32, 9, 0, 1) \
     X(__bf16, 64, 64, 64, CONV3, 8, 32, 4, 1, 64, 1, 0, 1)  \
     X(__bf16, 96, 96, 96, CONV3, 8, 32, 8, 1, 96, 1, 0, 0)  \
-    X(__bf16, 128, 128, 128, CONV3, 8, 16, 4, 1, 64, 1, 0, 0) \
+    X(__bf16, 128, 128, 128, CONV3, 8, 16, 4, 1, 128, 1, 0, 0) \
     X(__bf16, 192, 192, 192, CONV3, 8, 16, 4, 1, 64, 1, 0, 0) \
     X(__bf16, 256, 256, 256, CONV3, 16, 8, 4, 1, 32, 1, 0, 0) \
     X(__bf16, 128, 128, 64, CONV3, 8, 8, 2, 2, 128, 1, 1, 0)  \
     X(__bf16, 192, 192, 64, CONV3, 8, 16, 2, 2, 192, 1, 1, 0) \
-    X(__bf16, 256, 256, 64, CONV3, 8, 8, 2, 2, 128, 1, 1, 0) \
+    X(__bf16, 256, 256, 64, CONV3, 8, 8, 2, 2, 256, 1, 1, 0) \
     X(__bf16, 32, 32, 32, CONV3, 8, 32, 4, 1, 32, 9, 2, 0)  \
     X(__bf16, 32, 32, 32, CONV3, 8, 32, 4, 1, 32, 9, 3, 1)  \
     X(__bf16, 32, 32, 32, CONV3, 16, 32, 8, 1, 32, 9, 4, 0) \
