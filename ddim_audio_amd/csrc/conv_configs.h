@@ -30,7 +30,7 @@
     X(__bf16, 96, 96, 96, CONV3, 8, 32, 4, 1, 96, 1, 3, 1)
 
 #define DDIMX_DOWNUP_BF16(X)                           \
-    X(__bf16, 32, 64, 64, DOWN4, 8, 16, 4, 1, 32, 4, 0, 0)   \
+    X(__bf16, 32, 64, 64, DOWN4, 8, 16, 4, 2, 32, 16, 0, 0)  \
     X(__bf16, 64, 96, 96, DOWN4, 8, 16, 4, 1, 64, 1, 0, 0)   \
     X(__bf16, 96, 128, 128, DOWN4, 8, 8, 2, 2, 96, 1, 0, 0)  \
     X(__bf16, 128, 192, 192, DOWN4, 8, 8, 2, 2, 32, 1, 0, 0) \
@@ -39,7 +39,7 @@
     X(__bf16, 192, 256, 128, UP4, 8, 16, 4, 2, 96, 1, 0, 0)  \
     X(__bf16, 128, 192, 192, UP4, 8, 8, 2, 2, 64, 1, 0, 0)   \
     X(__bf16, 96, 128, 128, UP4, 8, 16, 4, 1, 96, 1, 0, 0)   \
-    X(__bf16, 64, 64, 64, UP4, 8, 32, 8, 1, 64, 1, 0, 0)     \
+    X(__bf16, 64, 64, 64, UP4, 16, 32, 8, 1, 64, 6, 0, 0)    \
     X(__bf16, 192, 256, 128, DOWN4, 4, 8, 1, 4, 96, 1, 1, 0)  \
     X(__bf16, 128, 192, 96, DOWN4, 4, 8, 1, 3, 128, 1, 1, 0)  \
     X(__bf16, 256, 384, 128, UP4, 8, 8, 2, 2, 128, 1, 1, 0)

@@ -48,7 +48,7 @@ for lvl in range(1, 6):
 
     for name, fn, y in (("down", down, yd), ("up", up, yu)):
         out, ref = [], None
-        for var in (None, 0, 1, 2, 3):
+        for var in (None, 0, 1, 2, 3, 4, 5):
             if var is None:
                 os.environ.pop("DDIMX_CONV_VAR", None)
             else:
