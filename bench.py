@@ -175,8 +175,23 @@ def main():
     ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU of the training leg (BASELINE config 4)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL world of N) through
+        # torch.distributed.run BEFORE anything in this process touches the GPU, wait, and pass their exit code on.  The parent
+        # never initialises HIP and never re-execs itself (a child process, not os.exec*).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: reporting n_gpus={world}", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
@@ -248,6 +263,7 @@ def main():
             "value": world * B * iters_per_s,
             "unit": "sample-fwd/s",
             "n_gpus": world,
+            "ranks": world,  # torch.distributed world size (RCCL ranks, one per GPU); 1 = no process group
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -16,7 +16,7 @@ class DdimxConfig(Structure):
         ("in_channels", c_int), ("f_size", c_int), ("n_levels", c_int),
         ("ch", c_int * MAX_LEVELS), ("res", c_int * MAX_LEVELS), ("krn", c_int * MAX_LEVELS),
         ("n_timesteps", c_int), ("fnet_hidden", c_int), ("fnet_layers", c_int), ("fnet_inter", c_int),
-        ("fnet_ln_eps", c_float), ("act_dtype", c_int),
+        ("fnet_ln_eps", c_float), ("act_dtype", c_int), ("fnet_dtype", c_int),
     ]
 
 
@@ -102,7 +102,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.ddimx_abi_version() != 1:
+        if lib.ddimx_abi_version() != 2:
             raise RuntimeError("libddimx ABI version mismatch")
         _lib = lib
     return _lib

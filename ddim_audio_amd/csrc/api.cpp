@@ -17,6 +17,22 @@
 #include "wgrad_mfma.h"
 
 namespace ddimx {
+// Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
+// library call that needs one, never per launch.
+struct Knobs {
+    int conv_var, conv_wps, wgrad_split, fnet_mix;
+    Knobs() {
+        auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        conv_var = geti("DDIMX_CONV_VAR", -1);
+        conv_wps = geti("DDIMX_CONV_WPS", 0);
+        wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
+        fnet_mix = geti("DDIMX_FNET_MIX", 1);
+    }
+};
+static const Knobs& knobs() {
+    static const Knobs k;
+    return k;
+}
 hipError_t conv_geometry_bf16_c3(int, int, int, int, ConvGeom*);
 hipError_t conv_geometry_bf16_du(int, int, int, int, ConvGeom*);
 hipError_t conv_geometry_f32_c3(int, int, int, int, ConvGeom*);
@@ -40,9 +56,8 @@ hipError_t conv_launch(int dtype, int mode, int cin, int cout, int var, ConvArgs
 }
 int conv_pick_variant(int dtype, int mode, int cin, int cout, int B, int Hv, int Wv) {
     ConvGeom g0, g1;
-    if (const char* e = getenv("DDIMX_CONV_VAR")) {  // tuning hook: force a candidate variant where one exists
-        const int v = atoi(e);
-        if (v >= 0 && conv_geometry(dtype, mode, cin, cout, v, &g0) == hipSuccess) return v;
+    if (const int v = knobs().conv_var; v >= 0) {  // tuning hook: force a candidate variant where one exists
+        if (conv_geometry(dtype, mode, cin, cout, v, &g0) == hipSuccess) return v;
     }
     if (conv_geometry(dtype, mode, cin, cout, 0, &g0) != hipSuccess) return 0;
     if (conv_geometry(dtype, mode, cin, cout, 1, &g1) != hipSuccess) return 0;
@@ -100,6 +115,7 @@ struct RBW {
 struct ddimx_ctx {
     ddimx_config cfg;
     int dtype;
+    int fnet_bf16;  // operands of the FNet's dense-weight GEMMs rounded to bf16 (transformers.dtype), else exact fp32 MFMA
     int L;
     int E;      // total timestep-embedding width
     int width;  // FNet token width
@@ -156,6 +172,9 @@ static int build_plan(ddimx_ctx* c) {
     c->dtype = f.act_dtype;
     if (L < 1 || L > DDIMX_MAX_LEVELS) return fail("n_levels %d out of range", L);
     if (f.act_dtype != DDIMX_F32 && f.act_dtype != DDIMX_BF16) return fail("act_dtype %d not supported", f.act_dtype);
+    if (f.fnet_dtype != DDIMX_F32 && f.fnet_dtype != DDIMX_BF16) return fail("fnet_dtype %d not supported", f.fnet_dtype);
+    if (f.fnet_dtype == DDIMX_BF16 && f.act_dtype != DDIMX_BF16) return fail("fnet_dtype bf16 needs act_dtype bf16");
+    c->fnet_bf16 = f.fnet_dtype == DDIMX_BF16;
     for (int l = 0; l < L; ++l) {
         if (f.krn[l] != 3) return fail("kernel size %d at level %d: only 3 is implemented", f.krn[l], l);
         if (f.ch[l] % 32) return fail("channel width %d at level %d must be a multiple of 32", f.ch[l], l);
@@ -323,7 +342,7 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
     w->Hb = (float*)cv.take(M * inter * 4);
     w->O = (float*)cv.take(M * c->width * 4);
     {   // split-K partial tiles of the skinny FNet GEMMs
-        const int bf = c->dtype == DT_BF16;
+        const int bf = c->fnet_bf16;
         const int shp[6][5] = {{(int)M, hid, c->width, 1, bf}, {2 * hid, S, hid, B, 0}, {S, hid, S, B, 0},
                                {(int)M, inter, hid, 1, bf}, {(int)M, hid, inter, 1, bf}, {(int)M, c->width, hid, 1, bf}};
         size_t mx = 0;
@@ -383,7 +402,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         if (tiles_s / 4 > wps) wps = tiles_s / 4;  // long spectrograms (T >= 2048): at most 4 tiles per workgroup, so that a
                                                    // single sample still fills the 256 CUs
         if (q.cin >= 64 && tiles_s >= 512 && wps < 256) wps = 256;  // streamed-weight levels of long samples: 2 tiles per workgroup
-        if (const char* e = getenv("DDIMX_CONV_WPS")) { const int v = atoi(e); if (v > 0) wps = v < tiles_s ? v : tiles_s; }
+        if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
         a.tiles_per_wg = cdiv(tiles_s, wps);
         a.wgs_per_sample = cdiv(tiles_s, a.tiles_per_wg);
     }
@@ -448,7 +467,7 @@ static void wgrad_plan(const WgradGeom& g, int B, int Hd, int Wd, int* tiles_x, 
     *tiles_y = cdiv(Hd, g.th);
     const int total = B * *tiles_x * *tiles_y;
     int want = 512 / g.grid_y;
-    if (const char* e = getenv("DDIMX_WGRAD_SPLIT")) { const int v = atoi(e); if (v > 0) want = v / g.grid_y; }  // tuning hook
+    if (const int v = knobs().wgrad_split; v > 0) want = v / g.grid_y;  // tuning hook
     if (want < 1) want = 1;
     if (want > total) want = total;
     *per = cdiv(total, want);
@@ -593,7 +612,7 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     const ddimx_config& f = c->cfg;
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
     const float eps = f.fnet_ln_eps;
-    const int bf = c->dtype == DT_BF16;
+    const int bf = c->fnet_bf16;
     HIPCHK(layernorm_launch(c->dtype, x, tb->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps, w.ln0, M,
                             width, s));
     CHK(fnet_gemm(w, s, w.ln0, pf(c, packed, c->proj_w), w.X, M, hid, width, width, width, hid, pf(c, packed, c->proj_b),
@@ -604,7 +623,7 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
         const ddimx_ctx::FL& L = c->fl[i];
         // Ut[b] = D_H * X[b]^T -> [2*hid][S]; D_H rows interleaved (2k: cos_k, 2k+1: sin_k), so that row pair k of
         // Ut[b] is one contiguous K-vector [cos-part(S) | sin-part(S)] for the sequence transform
-        if (fnet_mix_supported(S, hid) && !(getenv("DDIMX_FNET_MIX") && atoi(getenv("DDIMX_FNET_MIX")) == 0)) {
+        if (fnet_mix_supported(S, hid) && knobs().fnet_mix != 0) {
             HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, cur, w.Z, B, S, hid, s));
         } else {
         CHK(fnet_gemm(w, s, tb->dft_hidden, cur, w.Ut, 2 * hid, S, hid, hid, hid, S, nullptr, nullptr, 0, 0, 0, B, 0,
@@ -935,7 +954,7 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
     w->dTok = (float*)cv.take(M * width * 4);
     w->pgrad = (float*)cv.take(hid * width * 4);
     {   // split-K partial tiles: forward shapes and the backward GEMMs (weight gradients contract over M)
-        const int bf = dt == DT_BF16, Mi = (int)M, h = (int)hid, in = (int)inter, wd = (int)width;
+        const int bf = c->fnet_bf16, Mi = (int)M, h = (int)hid, in = (int)inter, wd = (int)width;
         const int shp[][5] = {{Mi, h, wd, 1, bf}, {2 * h, S, h, B, 0}, {S, h, 2 * S, B, 0}, {Mi, in, h, 1, bf}, {Mi, h, in, 1, bf},
                               {Mi, wd, h, 1, bf}, {wd, h, Mi, 1, bf}, {h, in, Mi, 1, bf}, {in, h, Mi, 1, bf}, {h, wd, Mi, 1, bf}};
         size_t mx = 0;
@@ -965,7 +984,7 @@ static int tgemm(const TrainWs& w, hipStream_t s, const float* A, const float* B
 static int fourier_mix(const ddimx_ctx* c, const ddimx_tables* tb, const TrainWs& w, const float* X, float* Z, int B, int S,
                        hipStream_t s) {
     const int hid = c->cfg.fnet_hidden;
-    if (fnet_mix_supported(S, hid) && !(getenv("DDIMX_FNET_MIX") && atoi(getenv("DDIMX_FNET_MIX")) == 0)) {
+    if (fnet_mix_supported(S, hid) && knobs().fnet_mix != 0) {
         HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, X, Z, B, S, hid, s));
         return 0;
     }
@@ -1102,7 +1121,7 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
     const int S = T >> (L - 1), CL = f.ch[L - 1];
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
     const float eps_ln = f.fnet_ln_eps;
-    const int bf = dt == DT_BF16;
+    const int bf = c->fnet_bf16;
     HIPCHK(ln_train_launch(dt, cur, tables->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps_ln, tp.ln0, nullptr,
                            tp.ln0_stat, M, width, 0.f, seed, 0, s));
     CHK(tgemm(w, s, tp.ln0, pf(c, packed, c->proj_w), tp.X0, M, hid, width, pf(c, packed, c->proj_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
@@ -1232,7 +1251,7 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
     // ---- bottleneck: up_in[L-1] = D_{L-1} + O
     const int S = T >> (L - 1), CL = f.ch[L - 1];
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
-    const int bf = dt == DT_BF16;
+    const int bf = c->fnet_bf16;
     const int C5 = CL, Fr = c->Fr;
     const void* Dlast = tp.dn_y[L - 1].back();
     HIPCHK(cast_f32_launch(dt, w.GS[L - 1], w.dO, (long long)M * width, s));

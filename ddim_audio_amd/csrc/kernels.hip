@@ -854,13 +854,13 @@ hipError_t grad_norm_multi_launch(const long long* ptrs, const long long* sizes,
 }
 
 // decoupled = 2: AdaBelief (Zhuang et al. 2020, weight_decouple, no rectification, no amsgrad): v <- b2 v + (1-b2)(g-m)^2 + eps.
-// g *= coef[1] (the clip coefficient stays on the device: no host sync), then Adam / AdamW (torch semantics,
+// g' = g * coef[1] in registers (the clip coefficient stays on the device: no host sync), then Adam / AdamW (torch semantics,
 // amsgrad off): decoupled: p *= 1 - lr*wd ; else g += wd*p.  m = m + (1-b1)(g - m); v = b2*v + (1-b2) g*g;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t) from the host.
 __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamArgs a) {
     const int ti = a.blk_tensor[blockIdx.x];
     float* p = (float*)a.p[ti];
-    float* g = (float*)a.g[ti];
+    const float* g = (const float*)a.g[ti];  // never written: torch.optim leaves p.grad alone (clip / L2 terms stay in registers)
     float* m = (float*)a.m[ti];
     float* v = (float*)a.v[ti];
     const long long n = a.sizes[ti], off = a.blk_off[blockIdx.x];
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamArgs a) {
         }
         const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vk), a.bc2s), a.eps);
         pk = fmaf(-step_size, __fdiv_rn(mk, denom), pk);
-        g[k] = gk; m[k] = mk; v[k] = vk; p[k] = pk;
+        m[k] = mk; v[k] = vk; p[k] = pk;
     }
 }
 __global__ void __launch_bounds__(256) scale_multi_kernel(const long long* __restrict__ ptrs, const long long* __restrict__ sizes,

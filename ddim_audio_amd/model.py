@@ -210,7 +210,11 @@ class _UNetTrainFn(torch.autograd.Function):
         out = torch.empty_like(x)
         p = float(getattr(model.config.transformers.kwargs, "hidden_dropout_prob", 0.0))
         model._dropout_calls = getattr(model, "_dropout_calls", 0) + 1
-        seed = (torch.initial_seed() * 0x9E3779B1 + model._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        # one mask stream per (process seed, data-parallel rank, forward call): ranks with the same manual seed must not
+        # draw the same masks; ``_dropout_calls`` travels with resume checkpoints (checkpoint.save_checkpoint)
+        import torch.distributed as tdist
+        rank = tdist.get_rank() if tdist.is_available() and tdist.is_initialized() else 0
+        seed = (torch.initial_seed() * 0x9E3779B1 + (rank * 0xC2B2AE3D27D4EB4F) + model._dropout_calls) & 0xFFFFFFFFFFFFFFFF
         tb = _lib.DdimxTables(tables[0].data_ptr(), tables[1].data_ptr(), tables[2].data_ptr())
         _lib.check(lib.ddimx_unet_fwd_train(model._handle, _lib.ptr(model._packed), ctypes.byref(tb), _lib.ptr(ws), ws.numel(),
                                             _lib.ptr(tape), tape.numel(), _lib.ptr(x), _lib.ptr(t), _lib.ptr(out), b, t_len, p, seed,
@@ -263,9 +267,13 @@ class Model(_Node):
         self.embedding_size = embedding_sizes(config.model)
         self._n_timesteps = config.diffusion.num_diffusion_timesteps
         dev, act = parse_tensor_type(getattr(config.model, "dtype", None))
+        # transformers.dtype (reference :242-246,267-279: the transformer is re-cast to its own dtype, which lets the convs run
+        # half while the FNet stays fp32 -- the reference's only workable half setup, fftn has no bf16).  It selects the operand
+        # type of the FNet's dense GEMMs; absent = fp32.
         tr_dtype = getattr(config.model.transformers, "dtype", None)
-        if tr_dtype:
-            parse_tensor_type(tr_dtype)  # validate; the FNet always computes in fp32 (reference :242-246,267-279)
+        self._fnet_dtype = parse_tensor_type(tr_dtype)[1] if tr_dtype else torch.float32
+        if self._fnet_dtype == torch.bfloat16 and act != torch.bfloat16:
+            raise NotImplementedError("transformers.dtype BFloat16Tensor needs model.dtype BFloat16Tensor")
         self._act_dtype = act
         self._handle = None
         self._packed = None
@@ -322,6 +330,7 @@ class Model(_Node):
         cfg.fnet_hidden, cfg.fnet_layers, cfg.fnet_inter = kw.hidden_size, kw.num_hidden_layers, kw.intermediate_size
         cfg.fnet_ln_eps = kw.layer_norm_eps
         cfg.act_dtype = _lib.DDIMX_BF16 if self._act_dtype == torch.bfloat16 else _lib.DDIMX_F32
+        cfg.fnet_dtype = _lib.DDIMX_BF16 if self._fnet_dtype == torch.bfloat16 else _lib.DDIMX_F32
         import ctypes
         h = ctypes.c_void_p()
         _lib.check(lib.ddimx_create(ctypes.byref(cfg), ctypes.byref(h)))
@@ -361,12 +370,15 @@ class Model(_Node):
         arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         _lib.check(lib.ddimx_pack_weights(self._handle, arr, len(tensors), _lib.ptr(self._packed), _lib.stream()))
         self._packed_key = key
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1  # every real repack; the backward packings follow this counter
         self._dirty = False
 
     def _ensure_packed_bwd(self, lib, device):
         """Backward-only weight packings (data-gradient conv layouts, transposed FNet matrices); follows _ensure_packed."""
         from . import _lib
-        if getattr(self, "_packed_bwd_key", None) == self._packed_key and getattr(self, "_packed_bwd", None) is not None:
+        # keyed on the repack generation, not on (data_ptr, _version): writes through ``p.data`` / raw pointers followed by
+        # invalidate() repack the forward weights without changing that tuple, and the backward packings must follow
+        if getattr(self, "_packed_bwd_gen", None) == self._pack_gen and getattr(self, "_packed_bwd", None) is not None:
             return
         tensors = self._state_tensors()
         if getattr(self, "_packed_bwd", None) is None or self._packed_bwd.device != device:
@@ -375,7 +387,7 @@ class Model(_Node):
         arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         _lib.check(lib.ddimx_pack_weights_bwd(self._handle, arr, len(tensors), _lib.ptr(self._packed), _lib.ptr(self._packed_bwd),
                                               _lib.stream()))
-        self._packed_bwd_key = self._packed_key
+        self._packed_bwd_gen = self._pack_gen
 
     def _grad_layout(self, lib):
         """(total floats, [(offset, numel, shape)] per parameter in named_parameters() order) of the flat gradient buffer."""

@@ -82,6 +82,32 @@ class FusedAdam(optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, decoupled=decoupled))
         self._tables = {}
 
+    # -- checkpoint wire format: interchangeable with torch.optim.Adam / AdamW (runners/diffusion.py:187,245-249) ----------
+    def state_dict(self):
+        """Same layout as ``torch.optim.AdamW.state_dict()``: per-parameter ``step`` as a 0-dim fp32 tensor, no
+        library-private keys in ``param_groups`` (``decoupled`` is a constructor property, like torch's class choice)."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (torch.tensor(float(v)) if n == "step" else v) for n, v in st.items()} for k, st in sd["state"].items()}
+        sd["param_groups"] = [{k: v for k, v in g.items() if k != "decoupled"} for g in sd["param_groups"]]
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """Accepts states written by this class and by ``torch.optim.Adam`` / ``AdamW`` (tensor ``step``, no ``decoupled`` key,
+        extra torch keys such as ``foreach`` / ``capturable`` are carried along untouched)."""
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            g.setdefault("decoupled", self.defaults["decoupled"])
+            if g.get("amsgrad"):
+                raise NotImplementedError("amsgrad is not implemented in the fused optimizer")
+            g["betas"] = tuple(g["betas"])
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = int(round(float(st["step"])))
+            for n in ("exp_avg", "exp_avg_sq"):
+                if n in st:
+                    st[n] = st[n].float().contiguous()
+        self._tables = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DDIMX_ABI_VERSION 1
+#define DDIMX_ABI_VERSION 2
 #define DDIMX_MAX_LEVELS 8
 #define DDIMX_F32 0
 #define DDIMX_BF16 1
@@ -45,7 +45,11 @@ typedef struct {
     int fnet_layers;                 /* transformers.kwargs.num_hidden_layers */
     int fnet_inter;                  /* transformers.kwargs.intermediate_size */
     float fnet_ln_eps;               /* transformers.kwargs.layer_norm_eps */
-    int act_dtype;                   /* DDIMX_F32 (parity mode) or DDIMX_BF16 */
+    int act_dtype;                   /* model.dtype: DDIMX_F32 (parity mode) or DDIMX_BF16 */
+    int fnet_dtype;                  /* transformers.dtype (models/diffusion.py:242-246): operand type of the FNet's dense-weight
+                                        GEMMs.  DDIMX_F32 = the reference's mixed mode (convs in act_dtype, transformer fp32);
+                                        DDIMX_BF16 = operands rounded to bf16 (needs act_dtype == DDIMX_BF16).  The DFT factors,
+                                        LayerNorms and accumulators are fp32 either way. */
 } ddimx_config;
 
 /* Host-built constant tables for a given T (device pointers, fp32):

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ddimx.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.ddimx_abi_version() == 1
+    assert lib.ddimx_abi_version() == 2
 
 
 def test_plan_matches_host_inventory_and_sizes():
