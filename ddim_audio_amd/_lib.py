@@ -21,7 +21,10 @@ class DdimxConfig(Structure):
 
 
 class DdimxTables(Structure):
-    _fields_ = [("posenc", c_void_p), ("dft_hidden", c_void_p), ("dft_seq", c_void_p)]
+    _fields_ = [("posenc", c_void_p), ("dft_hidden", c_void_p), ("dft_seq", c_void_p), ("temb_table", c_void_p)]
+
+    def __init__(self, posenc=None, dft_hidden=None, dft_seq=None, temb_table=None):
+        super().__init__(posenc, dft_hidden, dft_seq, temb_table)
 
 
 _SIGS = {
@@ -70,6 +73,11 @@ _SIGS = {
     "ddimx_upsample_add_fwd": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_int, c_void_p]),
     "ddimx_temb_fwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "ddimx_conv_in_stats_floats": (c_longlong, [c_int] * 4),
+    "ddimx_conv_in_fwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "ddimx_conv_out_fwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "ddimx_fnet_fwd": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int,
+                               c_void_p]),
     "ddimx_fnet_mix_supported": (c_int, [c_int, c_int]),
     "ddimx_fnet_mix": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_step_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

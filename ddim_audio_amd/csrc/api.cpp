@@ -728,9 +728,13 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
     hipStream_t s = (hipStream_t)stream;
     const int dt = c->dtype;
 
-    CHK(run_temb(pf(c, packed, c->te), t, pf(c, packed, c->tw[0]), pf(c, packed, c->tb[0]), pf(c, packed, c->tw[1]),
-                 pf(c, packed, c->tb[1]), pf(c, packed, c->tw[2]), pf(c, packed, c->tb[2]), w.temb_h1, w.temb_h2, w.temb,
-                 B, 128, 512, c->E, s));
+    if (tables->temb_table) {
+        HIPCHK(temb_gather_launch(tables->temb_table, t, w.temb, B, c->E, s));
+    } else {
+        CHK(run_temb(pf(c, packed, c->te), t, pf(c, packed, c->tw[0]), pf(c, packed, c->tb[0]), pf(c, packed, c->tw[1]),
+                     pf(c, packed, c->tb[1]), pf(c, packed, c->tw[2]), pf(c, packed, c->tb[2]), w.temb_h1, w.temb_h2, w.temb,
+                     B, 128, 512, c->E, s));
+    }
 
     // ---- down path (models/diffusion.py:252-264) ----
     HIPCHK(conv_in_launch(dt, x, pf(c, packed, c->in_w), pf(c, packed, c->in_b), w.A, w.stats, B, f.in_channels, f.ch[0], T,
@@ -1483,6 +1487,36 @@ int ddimx_upsample_add_fwd(int dtype, int Cin, int Cout, const void* x, const vo
     ConvCall u = {dtype, UP4, Cin, Cout, x, w, bias2, nullptr, 0, nullptr, nullptr, XF_NONE, 0, skip, y, nullptr, B, H, W};
     return run_conv(u, (hipStream_t)stream, nullptr, nullptr);
 }
+// ---- edge convolutions and the FNet bottleneck as single ops (the whole-network call runs exactly these) ----------
+long long ddimx_conv_in_stats_floats(int B, int C0, int H, int W) { return (long long)B * conv_in_nparts(H, W) * C0 * 2; }
+int ddimx_conv_in_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, float* stats, int B, int Cin, int C0,
+                      int H, int W, void* stream) {
+    if (!x || !w || !bias || !y || !stats) return fail("ddimx_conv_in_fwd: null argument");
+    HIPCHK(conv_in_launch(dtype, x, w, bias, y, stats, B, Cin, C0, H, W, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_conv_out_fwd(int dtype, const void* a, const void* b, const float* w_packed, const float* bias, float* eps, int B, int C0,
+                       int Cout, int H, int W, void* stream) {
+    if (!a || !b || !w_packed || !bias || !eps) return fail("ddimx_conv_out_fwd: null argument");
+    HIPCHK(conv_out_launch(dtype, a, b, w_packed, bias, eps, B, C0, Cout, H, W, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_fnet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
+                   const void* x, float* out, int B, int T, void* stream) {
+    if (!h || !packed || !tables || !workspace || !x || !out) return fail("ddimx_fnet_fwd: null argument");
+    const ddimx_ctx* c = h;
+    const int L = c->L;
+    if (B < 1 || T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("ddimx_fnet_fwd: bad shape B=%d T=%d", B, T);
+    Ws w;
+    carve(c, (char*)workspace, B, T, &w);
+    if ((long long)w.total > workspace_bytes) return fail("workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int S = T >> (L - 1);
+    CHK(run_fnet(c, packed, tables, w, x, B, S, s));
+    HIPCHK(hipMemcpyAsync(out, w.O, (size_t)B * S * c->width * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 int ddimx_temb_fwd(const float* te, const int64_t* t, const float* w0, const float* b0, const float* w1, const float* b1,
                    const float* w2, const float* b2, float* h1, float* h2, float* out, int B, int pos_ch, int emb_ch, int E,
                    void* stream) {

@@ -486,8 +486,13 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
                 const int s2 = wstage >= 1 ? wstage - 1 : 2;  // (wstage + 2) % 3: free since the last barrier
                 dma_issue((ch + 2) % C::NCHUNKS, s2);
                 chunk_mma(ch, wstage);
-                // this wave's part of chunk g+1 has landed once all but its DMA_PER_WAVE youngest VM ops are done
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DMA_PER_WAVE) : "memory");
+                // this wave's part of chunk g+1 has landed once all but its DMA_PER_WAVE youngest VM ops are done.
+                // lgkmcnt(0): this wave's ds_reads of chunk g must have RETURNED before the barrier releases the others --
+                // the next iteration's DMA overwrites a stage two barriers later at the earliest, but hipcc sinks the
+                // chunk's last MFMAs (and the lgkmcnt waits in front of them) below a raw s_barrier, which left reads of
+                // stage g in flight while another wave was already past the barrier; with a second kernel loading the
+                // CU's LDS pipeline (two streams) such a read was occasionally served after a later DMA had landed.
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::DMA_PER_WAVE) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 wstage = wstage == 2 ? 0 : wstage + 1;
@@ -602,6 +607,11 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     }
 
     DDIMX_STAMP_FLUSH();
+    // The weight ring runs two chunks ahead, so the last tile leaves two chunks of LDS-DMA in flight that nothing consumes.
+    // They must have landed before LDS is reused below (`red` overlays the ring): the compiler's barrier only waits for
+    // lgkmcnt (the DMA is inline asm, invisible to its waitcnt pass), and a DMA landing late -- seen when another kernel
+    // shares the CU -- would overwrite this workgroup's statistics.
+    if constexpr (!C::RESIDENT_W) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- statistics: one partial per workgroup -----------------------------------------------------------------
     if (a.stats) {  // uniform branch
         float* const red = (float*)smem;

@@ -37,6 +37,8 @@ hipError_t from_nhwc_launch(int dtype, const void* in, float* out, int B, int C,
 hipError_t linear_rows_launch(const float* x, const int64_t* idx, const float* W, const float* bias, float* y, int B,
                               int N, int K, int act_silu, hipStream_t s, int in_silu = 0);
 
+hipError_t temb_gather_launch(const float* table /*[n_timesteps][E]*/, const int64_t* t, float* out, int B, int E, hipStream_t s);
+
 // ---- LayerNorm over rows -----------------------------------------------------------------------------
 // y = LN(x [+ add[(m % add_rows)]]) * gamma + beta;  x is T (dtype) or fp32 (dtype = DT_F32)
 hipError_t layernorm_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma,

@@ -587,6 +587,21 @@ hipError_t linear_rows_launch(const float* x, const int64_t* idx, const float* W
     return hipGetLastError();
 }
 
+// rows of a precomputed [n_timesteps][E] timestep-embedding table: out[b] = table[t[b]]  (eval mode: the MLP of
+// models/diffusion.py:110-120 is a pure function of t, and all rows of a sampling step share one t)
+__global__ void __launch_bounds__(256) temb_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ t,
+                                                          float* __restrict__ out, int E) {
+    const int b = blockIdx.y;
+    const float4* src = (const float4*)(table + (size_t)t[b] * E);
+    float4* dst = (float4*)(out + (size_t)b * E);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < E / 4; i += gridDim.x * 256) dst[i] = src[i];
+}
+hipError_t temb_gather_launch(const float* table, const int64_t* t, float* out, int B, int E, hipStream_t s) {
+    if (E % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(temb_gather_kernel, dim3((E / 4 + 255) / 256, B), dim3(256), 0, s, table, t, out, E);
+    return hipGetLastError();
+}
+
 // =====================================================================================================
 // LayerNorm over rows (two-pass in registers: mean, then centred variance)
 // =====================================================================================================

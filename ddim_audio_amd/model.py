@@ -372,6 +372,34 @@ class Model(_Node):
         self._packed_key = key
         self._pack_gen = getattr(self, "_pack_gen", 0) + 1  # every real repack; the backward packings follow this counter
         self._dirty = False
+        self._temb_table = None
+        if not self.training:
+            self._build_temb_table(lib, device, tensors)
+
+    def _build_temb_table(self, lib, device, tensors):
+        """Eval mode: BetaEmbedding (reference :110-120) is a pure function of t, so its [n_timesteps, E] table is computed once
+        per weight set with the same kernels (``ddimx_temb_fwd`` over t = 0..n-1; rows are computed independently, so they are
+        bit-identical to a per-call evaluation) and the forward copies row t[b]."""
+        from . import _lib
+        names = list(self._inventory)
+        get = lambda n: tensors[names.index(n)]  # noqa: E731
+        n, e = self._n_timesteps, sum(self.embedding_size)
+        tt = torch.arange(n, dtype=torch.int64, device=device)
+        h1 = torch.empty(n, _EMB_CH, dtype=torch.float32, device=device)
+        h2 = torch.empty_like(h1)
+        out = torch.empty(n, e, dtype=torch.float32, device=device)
+        w = [get(f"temb.weight.{i}.{k}") for i in range(3) for k in ("weight", "bias")]
+        _lib.check(lib.ddimx_temb_fwd(_lib.ptr(get("temb.te")), _lib.ptr(tt), *[_lib.ptr(v) for v in w], _lib.ptr(h1), _lib.ptr(h2),
+                                      _lib.ptr(out), n, _POS_CH, _EMB_CH, e, _lib.stream()))
+        self._temb_table = out
+
+    def prepare(self, device, t_len):
+        """Pack weights / build tables for a [*, C, t_len, F] forward on the CURRENT stream.  The sampler calls this before it
+        forks its batch shards onto side streams, so that no shard races the packing launches of another."""
+        lib = self._ensure_handle()
+        with torch.cuda.device(device):
+            self._ensure_packed(lib, device)
+            self._ensure_tables(t_len, device)
 
     def _ensure_packed_bwd(self, lib, device):
         """Backward-only weight packings (data-gradient conv layouts, transposed FNet matrices); follows _ensure_packed."""
@@ -421,7 +449,12 @@ class Model(_Node):
         return self._tables[key]
 
     # -- forward -------------------------------------------------------------------------------------
-    def forward(self, input, t):
+    def forward_slot(self, input, t, slot):
+        """``forward`` over workspace ``slot``: concurrent calls on different HIP streams (the sampler's batch shards) must
+        not share scratch memory.  Inference only."""
+        return self.forward(input, t, _slot=slot)
+
+    def forward(self, input, t, _slot=0):
         """input [B, C, T, F] fp32 on the GPU, t [B] int64 -> eps [B, C, T, F] fp32 (reference :237-294).
         eval mode or no_grad: ``ddimx_unet_fwd``.  train mode with grad enabled: ``ddimx_unet_fwd_train`` (dropout active,
         tape kept) as an autograd node whose backward fills every parameter's gradient (``ddimx_unet_bwd``)."""
@@ -442,9 +475,12 @@ class Model(_Node):
             need = int(lib.ddimx_workspace_bytes(self._handle, b, t_len))
             if need <= 0:
                 raise RuntimeError("libddimx: bad workspace size for B=%d T=%d" % (b, t_len))
-            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-                self._workspace = None
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            if self._workspace is None:
+                self._workspace = {}
+            wsp = self._workspace.get(_slot)
+            if wsp is None or wsp.numel() < need or wsp.device != dev:
+                self._workspace.pop(_slot, None)
+                wsp = self._workspace[_slot] = torch.empty(need, dtype=torch.uint8, device=dev)
             x = input.contiguous()
             tt = t.to(device=dev, dtype=torch.int64).contiguous()
             if self.training and torch.is_grad_enabled():
@@ -454,9 +490,10 @@ class Model(_Node):
                 params = [p for _, p in self.named_parameters()]
                 return _UNetTrainFn.apply(self, x, tt, (pe, dh, ds), *params)
             out = torch.empty_like(x)
-            tables = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr())
+            tt_ptr = self._temb_table.data_ptr() if (not self.training and getattr(self, "_temb_table", None) is not None) else None
+            tables = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr(), tt_ptr)
             import ctypes
             _lib.check(lib.ddimx_unet_fwd(self._handle, _lib.ptr(self._packed), ctypes.byref(tables),
-                                          _lib.ptr(self._workspace), self._workspace.numel(), _lib.ptr(x), _lib.ptr(tt),
+                                          _lib.ptr(wsp), wsp.numel(), _lib.ptr(x), _lib.ptr(tt),
                                           _lib.ptr(out), b, t_len, _lib.stream()))
         return out

@@ -21,16 +21,29 @@ def _selected(select_index, index, n):
     return select_index is None or index in select_index or index - n in select_index
 
 
+def _default_branches(batch):
+    """Concurrent launch branches for a batch (DDIMX_BRANCHES overrides).  Every op of the path is per sample and the
+    launch plan depends on the sample's size only (a sample's result is bit-identical in any batch), so the batch can be cut
+    into contiguous shards that run the same step on separate HIP streams: the under-filled launches of one shard (GroupNorm
+    finalisation, the FNet's small GEMMs, levels 3-5 at small batches) overlap the other shard's full-chip convolutions."""
+    env = os.environ.get("DDIMX_BRANCHES")
+    if env:
+        return max(1, min(int(env), batch))
+    return 2 if batch >= 4 else 1
+
+
 class DDIMStepper:
     """One sampling run's device state and its step function.
 
     ``step()`` = reference ``functions/denoising.py:22-43`` for one iteration: timestep fill, model
     forward, fused x0-prediction + x_{t-1} update, counter advance.  The scalars come from a device
     table indexed by a device counter, so after the first (eager) step the same launch sequence is
-    captured once into a hipGraph and replayed for every later step.
+    captured once into a hipGraph and replayed for every later step.  The batch is cut into ``branches``
+    contiguous shards, each enqueued on its own stream between a fork and a join (parallel branches of the
+    captured graph); results do not depend on the cut (see ``_default_branches``).
     """
 
-    def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None):
+    def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None, branches=None):
         self.lib = _lib.load()
         self.model, self.xt = model, xt
         dev = xt.device
@@ -44,16 +57,39 @@ class DDIMStepper:
                           and not torch.cuda.is_current_stream_capturing())
         self.graph = None
         self.done = 0
+        from .dist import shard_bounds
+        nb = branches if branches is not None else _default_branches(xt.size(0))
+        if not hasattr(model, "forward_slot"):
+            nb = 1  # a plain callable / foreign module: one branch, called as model(x, t)
+        nb = max(1, min(nb, xt.size(0)))
+        self.bounds = [shard_bounds(xt.size(0), r, nb) for r in range(nb)]
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(nb - 1)]
 
-    def _launch(self, noise):
+    def _branch(self, k, noise):
         lib, st = self.lib, _lib.stream()
-        _lib.check(lib.ddimx_step_begin(_lib.ptr(self.coef), _lib.ptr(self.counter), _lib.ptr(self.t), self.t.numel(), st))
-        et = self.model(self.xt, self.t)
+        lo, hi = self.bounds[k]
+        xt, t, x0 = self.xt[lo:hi], self.t[lo:hi], self.x0[lo:hi]
+        _lib.check(lib.ddimx_step_begin(_lib.ptr(self.coef), _lib.ptr(self.counter), _lib.ptr(t), t.numel(), st))
+        et = self.model.forward_slot(xt, t, k) if len(self.bounds) > 1 else self.model(xt, t)
         if et.dtype != torch.float32 or not et.is_contiguous():
             et = et.float().contiguous()
-        _lib.check(lib.ddimx_ddim_update(_lib.ptr(self.xt), _lib.ptr(et), _lib.ptr(noise), _lib.ptr(self.x0), _lib.ptr(self.coef),
-                                         _lib.ptr(self.counter), self.xt.numel(), st))
-        _lib.check(lib.ddimx_step_end(_lib.ptr(self.counter), st))
+        nz = None if noise is None else noise[lo:hi]
+        _lib.check(lib.ddimx_ddim_update(_lib.ptr(xt), _lib.ptr(et), _lib.ptr(nz), _lib.ptr(x0), _lib.ptr(self.coef),
+                                         _lib.ptr(self.counter), xt.numel(), st))
+
+    def _launch(self, noise):
+        main = torch.cuda.current_stream(self.xt.device)
+        if self.side:
+            self.model.prepare(self.xt.device, self.xt.size(2))  # packing / tables on this stream, before the fork
+        for s in self.side:                      # fork
+            s.wait_stream(main)
+        for k in range(1, len(self.bounds)):
+            with torch.cuda.stream(self.side[k - 1]):
+                self._branch(k, noise)
+        self._branch(0, noise)
+        for s in self.side:                      # join
+            main.wait_stream(s)
+        _lib.check(self.lib.ddimx_step_end(_lib.ptr(self.counter), _lib.stream()))
 
     def rewind(self):
         """Restart the coefficient table (benchmark loops longer than the schedule)."""
@@ -65,7 +101,7 @@ class DDIMStepper:
         else:
             self._launch(self.noise_fn(self.xt) if self.noise_fn is not None else None)
             if self.use_graph and self.done == 0:
-                # step 0 ran eagerly (it also sized the model's workspace); capture one generic step
+                # step 0 ran eagerly (it also sized the model's workspaces); capture one generic step
                 torch.cuda.synchronize(self.xt.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

@@ -61,6 +61,10 @@ typedef struct {
     const float* posenc;
     const float* dft_hidden;
     const float* dft_seq;
+    const float* temb_table; /* optional (may be null): [n_timesteps][E] = BetaEmbedding(t) for every t (models/diffusion.py:
+                                110-120), built once per weight set with ddimx_temb_fwd over t = 0..n_timesteps-1; when given,
+                                ddimx_unet_fwd copies row t[b] instead of running the three-layer MLP (eval mode only: the
+                                rows are bit-identical to the MLP's, which computes every row independently) */
 } ddimx_tables;
 
 typedef struct ddimx_ctx* ddimx_handle;
@@ -189,6 +193,24 @@ int ddimx_upsample_add_fwd(int dtype, int Cin, int Cout, const void* x, const vo
 int ddimx_temb_fwd(const float* te, const int64_t* t, const float* w0, const float* b0, const float* w1,
                    const float* b1, const float* w2, const float* b2, float* h1, float* h2, float* out, int B,
                    int pos_ch, int emb_ch, int E, void* stream);
+
+/* Input convolution, `down_modules[0]` = Conv2d(C_io -> ch[0], k3, p1) (models/diffusion.py:189-198,255-256):
+ * x [B][Cin][H][W] fp32 (the reference's NCHW boundary) -> y [B][H][W][C0] NHWC in `dtype`; also writes the GroupNorm
+ * statistics partials of y into `stats` (ddimx_conv_in_stats_floats() floats).  w [C0][Cin][3][3] fp32 as stored. */
+long long ddimx_conv_in_stats_floats(int B, int C0, int H, int W);
+int ddimx_conv_in_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, float* stats, int B, int Cin,
+                      int C0, int H, int W, void* stream);
+/* Output convolution, `up_modules[-1]` = Conv2d(ch[0] -> C_io, k3, p1) applied to `x + hidden[0]`
+ * (models/diffusion.py:199-208,283-292): a, b NHWC [B][H][W][C0] in `dtype` (summed on the fly) -> eps [B][Cout][H][W] fp32.
+ * w_packed: [9][Cout][C0] fp32 = ddimx_pack_conv(DDIMX_F32, w, ..). */
+int ddimx_conv_out_fwd(int dtype, const void* a, const void* b, const float* w_packed, const float* bias, float* eps, int B,
+                       int C0, int Cout, int H, int W, void* stream);
+/* Transformer_Module.forward (models/diffusion.py:148-167: TransformerEmbedding :131-145, FNetEncoder x num_hidden_layers
+ * transformers modeling_fnet.py:138-279, compute_out), eval mode.  x: the bottleneck activation NHWC
+ * [B][S][Fr][C_last] in act_dtype viewed as tokens [B*S][width]; out: fp32 [B*S][width], both in the library's token
+ * order f*C_last + c (the reference's is c*Fr + f: models/diffusion.py:273-278).  workspace: ddimx_workspace_bytes(B, T). */
+int ddimx_fnet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
+                   const void* x, float* out, int B, int T, void* stream);
 
 /* ---- sampler (functions/denoising.py:10-52) ------------------------------------------------------- */
 /* coef [n_iter][6] fp32 rows (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1); step: device int counter.

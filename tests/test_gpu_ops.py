@@ -142,3 +142,104 @@ def test_fnet_fourier_mixing(b, s_len, hid):
         outs[fused] = z.cpu()
         G.check_close(outs[fused], want, G.F32, f"fourier mixing fused={fused}")
     assert 1 in outs or not lib.ddimx_fnet_mix_supported(s_len, hid)
+
+
+# ---- Transformer_Module as one op (ddimx_fnet_fwd) against the reference-generated G5 fixtures -------------------------
+_FNET_MODELS = {}
+
+
+def _fnet_model(act, fnet):
+    """The full-size network's parameters (hash fill by name, as oracle/make_golden.py gave the reference), packed once."""
+    import ddim_audio_amd as D
+    from ddim_audio_amd import configs
+    key = (act, fnet)
+    if key not in _FNET_MODELS:
+        _FNET_MODELS.clear()
+        m = synth.fill_module(D.Model(configs.audio_config(f"torch.cuda.{act}", f"torch.cuda.{fnet}"))).eval()
+        _FNET_MODELS[key] = m
+    return _FNET_MODELS[key]
+
+
+@pytest.mark.parametrize("act,fnet,mx,rms", [("FloatTensor", "FloatTensor", 1e-4, 2e-5),          # parity mode
+                                            ("BFloat16Tensor", "FloatTensor", 2e-2, 4e-3),        # the reference's mixed mode
+                                            ("BFloat16Tensor", "BFloat16Tensor", 6e-2, 1.2e-2)])  # bf16 GEMM operands
+@pytest.mark.parametrize("s", [4, 32, 96])
+def test_fnet_fwd_golden(golden, act, fnet, mx, rms, s):
+    """models/diffusion.py:148-167 (pos-enc + LayerNorm + projection + 12 FNet layers + compute_out) through ddimx_fnet_fwd
+    against `fnet_s{4,32,96}_y` written by the real reference (S = 96 exercises the rounded-up pos-enc table and the
+    two-GEMM Fourier path, S <= 32 the fused mixing kernel).  Gates relative to the std of the expected output; measured
+    worst cases on MI355X: fp32 3e-6 / 6e-7, bf16 activations + fp32 FNet 6e-3 / 1.3e-3 (only the token rounding),
+    bf16 operands 2.3e-2 / 4.5e-3."""
+    import ctypes
+    lib = _lib.load()
+    m = _fnet_model(act, fnet)
+    dev = G.dev()
+    t_len = s * 32
+    lib2 = m._ensure_handle()
+    with torch.cuda.device(dev):
+        m._ensure_packed(lib2, dev)
+        pe, dh, ds = m._ensure_tables(t_len, dev)
+    tok = synth.gaussian(f"fnet.x{s}", (1, s, 2048))
+    # reference token order c*8 + f (models/diffusion.py:273-278)  ->  NHWC rows [S][Fr=8][C=256]
+    x = tok.view(1, s, 256, 8).permute(0, 1, 3, 2).contiguous().to(dev, m._act_dtype)
+    ws = torch.empty(int(lib.ddimx_workspace_bytes(m._handle, 1, t_len)), dtype=torch.uint8, device=dev)
+    out = torch.full((s, 2048), float("nan"), device=dev)
+    tb = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr())
+    _lib.check(lib.ddimx_fnet_fwd(m._handle, _lib.ptr(m._packed), ctypes.byref(tb), _lib.ptr(ws), ws.numel(), _lib.ptr(x), _lib.ptr(out),
+                                  1, t_len, _lib.stream()))
+    y = out.cpu().view(1, s, 8, 256).permute(0, 1, 3, 2).reshape(1, s, 2048)
+    want = torch.from_numpy(golden("model")[f"fnet_s{s}_y"]).double().reshape(-1)
+    got = y.double().reshape(-1)
+    assert torch.isfinite(got).all()
+    sd = float(want.std())
+    e_mx, e_rms = float((got - want).abs().max()) / sd, float((got - want).square().mean().sqrt()) / sd
+    print(f"[fnet_fwd {act}/{fnet} S={s}] max {e_mx:.2e} rms {e_rms:.2e} of std")
+    assert e_mx <= mx and e_rms <= rms, (act, fnet, s, e_mx, e_rms)
+
+
+# ---- edge convolutions as single ops -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("cin,c0,hw,b", [(2, 32, (40, 256), 2), (2, 32, (7, 24), 3), (2, 64, (9, 16), 2)])
+def test_conv_in_fwd_vs_oracle(dt, cin, c0, hw, b):
+    """`down_modules[0]` (models/diffusion.py:189-198): NCHW fp32 -> NHWC, plus the GroupNorm partials of its output."""
+    lib = _lib.load()
+    h, w = hw
+    sd = synth.fill_state_dict({"cin.weight": torch.empty(c0, cin, 3, 3), "cin.bias": torch.empty(c0)})
+    x = synth.gaussian(f"cin.x{c0}.{h}", (b, cin, h, w))
+    want = torch.nn.functional.conv2d(x, sd["cin.weight"], sd["cin.bias"], padding=1)
+    y = torch.empty((b, h, w, c0), dtype=G.TORCH_DT[dt], device=G.dev())
+    n_st = int(lib.ddimx_conv_in_stats_floats(b, c0, h, w))
+    stats = torch.full((n_st,), float("nan"), device=G.dev())
+    xg, wg, bg = G.g(x), G.g(sd["cin.weight"]), G.g(sd["cin.bias"])
+    _lib.check(lib.ddimx_conv_in_fwd(dt, _lib.ptr(xg), _lib.ptr(wg), _lib.ptr(bg), _lib.ptr(y), _lib.ptr(stats), b, cin, c0, h, w,
+                                     _lib.stream()))
+    got = G.from_nhwc(y, dt)
+    G.check_close(got, want, dt, f"conv_in {cin}->{c0} {hw}")
+    # statistics slabs [B][nparts][C0][2] = per-channel (sum, sum of squares) of the values as stored
+    st = stats.cpu().view(b, -1, c0, 2).double().sum(1)
+    ref = got.double()
+    assert torch.allclose(st[..., 0], ref.sum((2, 3)), rtol=1e-4, atol=1e-2 * h * w ** 0.5)
+    assert torch.allclose(st[..., 1], ref.square().sum((2, 3)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("c0,cout,hw,b", [(32, 2, (40, 256), 2), (32, 2, (9, 24), 3), (40, 2, (10, 16), 2)])
+def test_conv_out_fwd_vs_oracle(dt, c0, cout, hw, b):
+    """`up_modules[-1]` applied to `x + hidden[0]` (models/diffusion.py:199-208,283-292): two NHWC tensors -> NCHW fp32."""
+    lib = _lib.load()
+    h, w = hw
+    sd = synth.fill_state_dict({"cout.weight": torch.empty(cout, c0, 3, 3), "cout.bias": torch.empty(cout)})
+    a = synth.gaussian(f"cout.a{c0}.{h}", (b, c0, h, w))
+    s = synth.gaussian(f"cout.b{c0}.{h}", (b, c0, h, w)) * 0.7
+    an, sn = G.to_nhwc(a, dt), G.to_nhwc(s, dt)
+    a_r, s_r = G.from_nhwc(an, dt), G.from_nhwc(sn, dt)  # the operands as the kernel sees them (rounded in bf16 mode)
+    # bf16 mode: the 32-channel kernel stages the sum in the activation dtype (one more bf16 rounding, like `x + hidden[0]`
+    # on bf16 tensors), the generic kernel keeps the fp32 sum; fp32 accumulation either way
+    ssum = (a_r + s_r).bfloat16().float() if (dt == G.BF16 and c0 == 32) else a_r + s_r
+    want = torch.nn.functional.conv2d(ssum, sd["cout.weight"], sd["cout.bias"], padding=1)
+    wp = G.pack_conv(sd["cout.weight"], G.F32)
+    bg = G.g(sd["cout.bias"])
+    eps = torch.full((b, cout, h, w), float("nan"), device=G.dev())
+    _lib.check(lib.ddimx_conv_out_fwd(dt, _lib.ptr(an), _lib.ptr(sn), _lib.ptr(wp), _lib.ptr(bg), _lib.ptr(eps), b, c0, cout, h, w,
+                                      _lib.stream()))
+    G.check_close(eps.cpu(), want, G.F32, f"conv_out {c0}->{cout} {hw}")
