@@ -121,3 +121,27 @@ def tiny_dict(dtype="torch.cuda.FloatTensor", fnet_dtype=None):
 
 def tiny_config(dtype="torch.cuda.FloatTensor", fnet_dtype=None):
     return dict2namespace(tiny_dict(dtype, fnet_dtype))
+
+
+def micro_dict(dtype="torch.cuda.FloatTensor", fnet_dtype=None):
+    """The smallest network the kernels are instantiated for (two levels, one block each, one FNet layer): used for the
+    reference-written checkpoint fixture (tests/golden/ckpt_micro.pth, about 0.7 M parameters).  The optimizer groups are
+    listed default-first so that the reference's checkpoint -- which keeps only the LAST optimizer of its dict
+    (runners/diffusion.py:162-189) -- carries the small transformer group."""
+    d = audio_dict(dtype, fnet_dtype)
+    m = d["model"]
+    m["ch"] = [32, 64]
+    m["krn"] = [3, 3]
+    m["res"] = [1, 1]
+    m["f_size"] = 8
+    m["t_size"] = 8
+    m["transformers"]["kwargs"].update(hidden_size=32, num_hidden_layers=1, intermediate_size=64)
+    m["transformers"]["channels"] = 32
+    o = d["optimization"]["optimizer"]
+    d["optimization"]["optimizer"] = {"default": o["default"], "transformer": o["transformer"]}
+    d["optimization"]["optimizer"]["default"]["optimizer"] = "Adam"  # AdaBelief's source is absent upstream (un-vendored submodule)
+    return d
+
+
+def micro_config(dtype="torch.cuda.FloatTensor", fnet_dtype=None):
+    return dict2namespace(micro_dict(dtype, fnet_dtype))

@@ -296,9 +296,76 @@ def g8_train(out):
         out["step_group_sizes"] = np.asarray([len(g.params) for g in groups.values()])
 
 
+def g9_checkpoint(out):
+    """A checkpoint WRITTEN BY THE REFERENCE (Diffusion.train_step, runners/diffusion.py:130-199, saves at step 1) for the
+    micro configuration, copied to tests/golden/ckpt_micro.pth, and what the reference's own sampling path makes of it
+    (Diffusion.sample :293-313,331: strict load, EMA swap-in, eval; then generalized_steps)."""
+    import logging
+    import shutil
+    import tempfile
+    cfgd = configs.micro_dict(CPU)
+    cfgd["model"]["transformers"]["kwargs"]["hidden_dropout_prob"] = 0.0
+    cfg = configs.dict2namespace(cfgd)
+    cfg.tb_logger = types.SimpleNamespace(add_scalar=lambda *a, **k: None)
+    tmp = tempfile.mkdtemp()
+    args = types.SimpleNamespace(log_path=tmp)
+    runner = ref_runner.Diffusion(args, cfg, device=torch.device("cpu"))
+    model = filled(ref_model.Model(cfg), seed=11)
+    optimizers, schedulers = {}, {}
+    for name, p_opt in ref_runner.classify_group(cfg.optimization.optimizer, model).items():
+        optimizers[name] = optimizer = ref_functions.get_optimizer(p_opt.config, p_opt.params)
+        scheduler = ref_functions.get_scheduler(p_opt.config, optimizer)
+        if scheduler:
+            schedulers[name] = scheduler
+    grad_group = dict(ref_runner.classify_group(cfg.optimization.grad_norm, model))
+    ema_helper = ref_ema.EMAHelper(mu=cfg.model.ema_rate)
+    ema_helper.register(model)
+    x = synth.gaussian("ckpt.x", (2, 2, 8, 8))
+    torch.manual_seed(99)
+    logging.disable(logging.CRITICAL)
+    runner.train_step(model, x, optimizers, schedulers, grad_group, ema_helper, 1, 0)   # step 1 -> writes ckpt_1.pth, ckpt.pth
+    logging.disable(logging.NOTSET)
+    dst = os.path.join(OUT, "ckpt_micro.pth")
+    shutil.copyfile(os.path.join(tmp, "ckpt.pth"), dst)
+    states = torch.load(dst, weights_only=False)
+    out["n_states"] = np.asarray(len(states))
+    out["epoch"], out["step"] = np.asarray(states[2]), np.asarray(states[3])
+    out["optim_groups"] = np.asarray(list(optimizers.keys()))
+    last = list(optimizers.values())[-1]
+    out["optim_last_n_state"] = np.asarray(len(states[1]["state"]))
+    out["optim_last_lr"] = np.asarray(states[1]["param_groups"][0]["lr"], dtype=np.float64)
+    k0 = sorted(states[1]["state"].keys())[0]
+    out["optim_last_exp_avg0"] = np32(states[1]["state"][k0]["exp_avg"]).reshape(-1)[:64]
+    out["optim_last_step0"] = np.asarray(float(states[1]["state"][k0]["step"]))
+    # --- the reference's sampling path on that file
+    m2 = ref_model.Model(cfg)
+    m2.load_state_dict(states[0], strict=True)
+    eh = ref_ema.EMAHelper(mu=cfg.model.ema_rate)
+    eh.register(m2)
+    eh.load_state_dict(states[-1])
+    eh.ema(m2)
+    m2.eval()
+    xs0 = synth.gaussian("ckpt.sample.x", (2, 2, 8, 8))
+    seq = list(range(0, 1000, 100))
+    with _GpuSemantics():
+        xs, x0 = ref_denoise.generalized_steps(xs0.clone(), seq, m2, runner.alphas, None, eta=0.0)
+    out["sample_final"] = np32(xs[-1])
+    out["sample_x0_last"] = np32(x0[-1])
+    with torch.no_grad():
+        out["ema_model_y"] = np32(m2(synth.gaussian("ckpt.fwd.x", (2, 2, 8, 8)), torch.tensor([3, 777])))
+    shutil.rmtree(tmp)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["ckpt"]:  # only the checkpoint fixture
+        ck = {}
+        g9_checkpoint(ck)
+        np.savez_compressed(os.path.join(OUT, "ckpt.npz"), **ck)
+        for f in ("ckpt.npz", "ckpt_micro.pth"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+        return
     if sys.argv[1:] == ["train"]:  # only the training fixtures (the others are unchanged)
         train = {}
         g8_train(train)
@@ -319,6 +386,9 @@ def main():
     train = {}
     g8_train(train)
     np.savez_compressed(os.path.join(OUT, "train.npz"), **train)
+    ck = {}
+    g9_checkpoint(ck)
+    np.savez_compressed(os.path.join(OUT, "ckpt.npz"), **ck)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

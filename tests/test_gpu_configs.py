@@ -376,3 +376,57 @@ def test_conv_results_do_not_depend_on_concurrent_kernels():
                 torch.cuda.synchronize()
                 bad += sum(0 if torch.equal(o, ref) else 1 for o in outs)
             assert bad == 0, f"{name}: {bad}/24 runs differ from the quiet run while another stream is busy"
+
+
+# ------------------------------------------------------------------------------------------------- checkpoints
+def test_reference_written_checkpoint_samples_like_the_reference(golden, tmp_path):
+    """tests/golden/ckpt_micro.pth was written by the reference's own ``Diffusion.train_step``
+    (oracle/make_golden.py::g9_checkpoint).  Loaded here with ``strict=True`` plus the EMA swap-in
+    (runners/diffusion.py:293-313,331), the HIP path must reproduce the forward and the 10-step DDIM trajectory that the
+    reference itself produced from that file."""
+    import shutil
+    from ddim_audio_amd import checkpoint
+    g = golden("ckpt")
+    shutil.copyfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_micro.pth"), tmp_path / "ckpt.pth")
+    cfg = configs.micro_config("torch.cuda.FloatTensor")
+    m, ema = checkpoint.load_for_sampling(str(tmp_path), D.Model(cfg), use_ema=True, ema_rate=cfg.model.ema_rate, map_location="cuda")
+    assert not m.training
+    with torch.no_grad():
+        y = m(synth.gaussian("ckpt.fwd.x", (2, 2, 8, 8)).cuda(), torch.tensor([3, 777]).cuda())
+    G.check_close(y.cpu(), g["ema_model_y"], G.F32, "forward from the reference-written checkpoint")
+    alphas = make_schedule(cfg.diffusion)[1]
+    xs, x0 = D.generalized_steps(synth.gaussian("ckpt.sample.x", (2, 2, 8, 8)).cuda(), list(range(0, 1000, 100)), m, alphas, None, eta=0.0)
+    G.check_close(xs[-1], g["sample_final"], G.F32, "sample from the reference-written checkpoint", scale=10.0)
+    G.check_close(x0[-1], g["sample_x0_last"], G.F32, "x0 prediction from the reference-written checkpoint", scale=10.0)
+
+
+def test_training_resume_is_bit_exact(tmp_path):
+    """Fixed-forward resume (runners/diffusion.py:239-254): train 2 steps, save, train a 3rd (A); a fresh model + state resumed
+    from the file trains the same 3rd step (B).  A and B must agree bit for bit -- both optimizers' moments and step counts,
+    both LambdaLR schedulers, the EMA shadow and the dropout call counter (bf16 mode, dropout 0.1) all travel."""
+    from ddim_audio_amd import checkpoint, train
+    d = configs.tiny_dict("torch.cuda.BFloat16Tensor")
+    d["optimization"]["optimizer"]["default"]["optimizer"] = "AdamW"
+    d["optimization"]["optimizer"]["default"]["warmup"] = 3
+    cfg = configs.dict2namespace(d)
+    alphas = make_schedule(cfg.diffusion)[1].cuda()
+    xs = [synth.gaussian(f"resume.x{i}", (4, 2, 32, 32)).cuda() for i in range(3)]
+    es = [synth.gaussian(f"resume.e{i}", (4, 2, 32, 32)).cuda() for i in range(3)]
+    ts = [torch.tensor([10 + i, 500, 989 - i, 250]) for i in range(3)]
+    torch.manual_seed(77)
+    m = synth.fill_module(D.Model(cfg), 11)
+    st = train.TrainingState(cfg, m)
+    for i in range(2):
+        train.train_step(m, xs[i], st, alphas, e=es[i], t=ts[i])
+    checkpoint.save_checkpoint(str(tmp_path), m, st.optimizers, 0, 2, st.ema_helper, st.schedulers)
+    loss_a, _ = train.train_step(m, xs[2], st, alphas, e=es[2], t=ts[2])
+    m2 = D.Model(cfg)
+    st2 = train.TrainingState(cfg, m2)
+    assert checkpoint.resume_training(str(tmp_path), m2, st2.optimizers, st2.schedulers, st2.ema_helper, map_location="cuda") == (0, 2)
+    loss_b, _ = train.train_step(m2, xs[2], st2, alphas, e=es[2], t=ts[2])
+    assert float(loss_a) == float(loss_b)
+    for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), n
+        assert torch.equal(st.ema_helper.shadow[n], st2.ema_helper.shadow[n]), n
+    for k in st.optimizers:
+        assert st.optimizers[k].param_groups[0]["lr"] == st2.optimizers[k].param_groups[0]["lr"]

@@ -222,3 +222,98 @@ def test_classify_group_and_antithetic_timesteps():
     g = torch.Generator().manual_seed(5)
     t = train.antithetic_timesteps(5, 1000, g)
     assert t.shape == (5,) and int(t[0] + t[3]) == 999 and int(t[1] + t[4]) == 999
+
+
+# ---- checkpoint wire format: a file written by the reference's own train_step (tests/golden/ckpt_micro.pth) ----------------
+def _micro_cpu():
+    from ddim_audio_amd.model import Model
+    d = configs.micro_dict("torch.FloatTensor")
+    d["model"]["transformers"]["kwargs"]["hidden_dropout_prob"] = 0.0
+    cfg = configs.dict2namespace(d)
+    return cfg, Model(cfg)
+
+
+def test_reference_written_checkpoint_loads_strictly_and_oracle_reproduces_its_sampling(golden, tmp_path):
+    """runners/diffusion.py:293-313,331 on the reference-written file: strict load into this package's Model, EMA swap-in
+    (states[-1]), then the CPU oracle over the loaded parameters reproduces what the reference's own Model /
+    generalized_steps produced from the same file (tests/golden/ckpt.npz)."""
+    import shutil
+    from ddim_audio_amd import checkpoint, synth
+    from oracle import ref_cpu
+    g = golden("ckpt")
+    shutil.copyfile(os.path.join(REPO, "tests", "golden", "ckpt_micro.pth"), tmp_path / "ckpt.pth")
+    cfg, m = _micro_cpu()
+    states = torch.load(tmp_path / "ckpt.pth", weights_only=True)
+    assert len(states) == int(g["n_states"]) == 5 and states[2] == int(g["epoch"]) and states[3] == int(g["step"])
+    assert list(states[0].keys()) == list(m.state_dict().keys())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m, ema = checkpoint.load_for_sampling(str(tmp_path), m, use_ema=True, ema_rate=cfg.model.ema_rate)
+    assert not m.training and ema is not None
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    assert any(not torch.equal(sd[k], before[k]) for k in sd)
+    for k, v in states[-1].items():  # the EMA shadow is what sits in the parameters now
+        assert torch.equal(sd[k], v)
+    with torch.no_grad():
+        y = ref_cpu.model_forward(sd, cfg, synth.gaussian("ckpt.fwd.x", (2, 2, 8, 8)), torch.tensor([3, 777]))
+    want = torch.from_numpy(g["ema_model_y"])
+    assert float((y - want).abs().max()) <= 2e-5 * float(want.std())
+    alphas = schedule.make_schedule(cfg.diffusion)[1]
+    xs, x0 = ref_cpu.generalized_steps(synth.gaussian("ckpt.sample.x", (2, 2, 8, 8)), list(range(0, 1000, 100)),
+                                       lambda a, b: ref_cpu.model_forward(sd, cfg, a, b), alphas, None, eta=0.0)
+    for got, name in ((xs[-1], "sample_final"), (x0[-1], "sample_x0_last")):
+        want = torch.from_numpy(g[name])
+        assert float((got - want).abs().max()) <= 2e-4 * float(want.std()), name
+
+
+def test_resume_training_from_reference_and_own_checkpoints(golden, tmp_path):
+    """The fixed-forward resume (runners/diffusion.py:239-254 cannot run upstream): from the reference-written file it
+    restores the model, the LAST optimizer group (the only one that file holds), epoch / step, the EMA shadow and the
+    LambdaLR factors; from a file written here it restores every optimizer and scheduler, and that file still loads in
+    torch.optim.AdamW (the reference's optimizer class) unchanged."""
+    import shutil
+    from ddim_audio_amd import checkpoint, train
+    g = golden("ckpt")
+    shutil.copyfile(os.path.join(REPO, "tests", "golden", "ckpt_micro.pth"), tmp_path / "ckpt.pth")
+    cfg, m = _micro_cpu()
+    state = train.TrainingState(cfg, m)
+    assert list(state.optimizers.keys()) == [str(s) for s in g["optim_groups"]]
+    epoch, step = checkpoint.resume_training(str(tmp_path), m, state.optimizers, state.schedulers, state.ema_helper)
+    assert (epoch, step) == (int(g["epoch"]), int(g["step"])) == (0, 1)
+    last = list(state.optimizers.values())[-1]
+    assert len(last.state) == int(g["optim_last_n_state"])
+    first = last.state[last.param_groups[0]["params"][0]]
+    assert first["step"] == int(g["optim_last_step0"]) == 1 and isinstance(first["step"], int)
+    assert np.allclose(first["exp_avg"].reshape(-1)[:64].numpy(), g["optim_last_exp_avg0"], rtol=0, atol=0)
+    assert abs(last.param_groups[0]["lr"] - float(g["optim_last_lr"])) <= 1e-12
+    first_group = list(state.optimizers.values())[0]
+    assert len(first_group.state) == 0  # the reference's file has nothing for it
+    for name, sch in state.schedulers.items():  # LR factors re-derived from the step count
+        w = getattr(cfg.optimization.optimizer, name).warmup
+        base = getattr(cfg.optimization.optimizer, name).lr
+        assert abs(sch.optimizer.param_groups[0]["lr"] - base * min(((1 + step) / w) ** -0.5, (1 + step) / w)) <= 1e-15
+    states = torch.load(tmp_path / "ckpt.pth", weights_only=True)
+    assert all(torch.equal(state.ema_helper.shadow[k], v) for k, v in states[-1].items())
+    # ---- a checkpoint written here: every group travels, and torch's own optimizer reads states[1]
+    for o in state.optimizers.values():
+        for p in o.param_groups[0]["params"]:
+            o.state[p] = {"step": 7, "exp_avg": torch.full_like(p, 0.25), "exp_avg_sq": torch.full_like(p, 0.5)}
+    for s in state.schedulers.values():
+        s.last_epoch = 7
+    m._dropout_calls = 42
+    out = tmp_path / "own"
+    checkpoint.save_checkpoint(str(out), m, state.optimizers, 3, 7, state.ema_helper, state.schedulers)
+    saved = torch.load(out / "ckpt.pth", weights_only=False)
+    assert len(saved) == 5 and saved[2:4] == [3, 7] and os.path.exists(out / "ckpt_7.pth")
+    ref_opt = torch.optim.AdamW(list(state.optimizers.values())[-1].param_groups[0]["params"], lr=1.0)
+    ref_opt.load_state_dict(saved[1])  # the extra resume key is ignored by torch
+    st0 = ref_opt.state[ref_opt.param_groups[0]["params"][0]]
+    assert float(st0["step"]) == 7.0 and float(st0["exp_avg"].reshape(-1)[0]) == 0.25
+    cfg2, m2 = _micro_cpu()
+    state2 = train.TrainingState(cfg2, m2)
+    assert checkpoint.resume_training(str(out), m2, state2.optimizers, state2.schedulers, state2.ema_helper) == (3, 7)
+    assert m2._dropout_calls == 42
+    for k, o in state2.optimizers.items():
+        assert len(o.state) == len(state.optimizers[k].state) > 0
+        assert all(s["step"] == 7 and float(s["exp_avg_sq"].reshape(-1)[0]) == 0.5 for s in o.state.values())
+    assert all(s.last_epoch == 7 for s in state2.schedulers.values())
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
