@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+MFMA_F32_PEAK_TF = 157.3    # fp32-input MFMA = the fp32 vector rate
 
 
 def per_kernel_times(model, B, T, reps=20):
@@ -83,11 +84,32 @@ def per_kernel_times(model, B, T, reps=20):
                                               _lib.ptr(stats), B, H, W, st))
 
         elems = B * H * W * C
-        tc, tr = 0.5 * (timed(conv) + timed(conv2)), timed(resid)
+        tc1, tc2, tr = timed(conv), timed(conv2), timed(resid)
+        tc = 0.5 * (tc1 + tc2)
         rows.append(dict(kernel=f"conv_mfma_kernel<{'bf16' if bf16 else 'f32'},C={C},3x3>", level=lvl, launches_per_fwd=4 * res,
-                         seconds=tc, alg_bytes=2 * elems * es + 9 * C * C * es, flops=2.0 * elems * 9 * C))
+                         seconds=tc, seconds_k1=tc1, seconds_k2=tc2, alg_bytes=2 * elems * es + 9 * C * C * es, flops=2.0 * elems * 9 * C))
         rows.append(dict(kernel=f"resid_kernel<{'bf16' if bf16 else 'f32'},C={C}>", level=lvl, launches_per_fwd=2 * res,
                          seconds=tr, alg_bytes=3 * elems * es, flops=3.0 * elems))
+        if lvl > 0:  # Downsample (level lvl-1 -> lvl) and Upsample + skip add (lvl -> lvl-1): models/diffusion.py:59-78,284
+            Cp, Hp, Wp = m.ch[lvl - 1], H * 2, W * 2
+            xp = torch.randn(B, Hp, Wp, Cp, device=dev).to(tdt)
+            wd = (torch.randn(16 * C * Cp, device=dev) * (1.0 / (16 * Cp) ** 0.5)).to(tdt)
+            wu = (torch.randn(2 * 6 * 2 * Cp * C, device=dev) * (1.0 / (16 * C) ** 0.5)).to(tdt)
+            bu = torch.randn(2 * Cp, device=dev) * 0.1
+            zp = torch.empty_like(xp)
+
+            def down():
+                _lib.check(lib.ddimx_downsample_fwd(dt, Cp, C, _lib.ptr(xp), _lib.ptr(wd), _lib.ptr(bias), _lib.ptr(y), B, Hp, Wp, st))
+
+            def up():
+                _lib.check(lib.ddimx_upsample_add_fwd(dt, C, Cp, _lib.ptr(x), _lib.ptr(wu), _lib.ptr(bu), _lib.ptr(xp), _lib.ptr(zp), B, H, W, st))
+
+            ep = B * Hp * Wp * Cp
+            rows.append(dict(kernel=f"conv_mfma_kernel<down4 {Cp}->{C}>", level=lvl, launches_per_fwd=1, seconds=timed(down),
+                             alg_bytes=(ep + elems) * es + 16 * C * Cp * es, flops=2.0 * elems * 16 * Cp))
+            rows.append(dict(kernel=f"conv_mfma_kernel<up4 {C}->{Cp} + skip>", level=lvl, launches_per_fwd=1, seconds=timed(up),
+                             alg_bytes=(elems + 2 * ep) * es + 16 * C * Cp * es, flops=2.0 * ep * 4 * C))
+            del xp, zp
         del x, y, h, stats
     return rows
 
@@ -150,7 +172,16 @@ def training_leg(args, cfg, dev, rank, world, backend, steps=3):
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dt = float(el.item()) / steps
-        res = {"value": world * b / dt, "unit": "train samples/s", "ms_per_step": dt * 1e3, "batch_per_gpu": b, "t_size": args.t_size,
+        ar_ms = None
+        if world > 1 and getattr(m, "_flat_grad", None) is not None:  # the step's only collective, timed alone
+            torch.cuda.synchronize()
+            dist.barrier()
+            ta = time.perf_counter()
+            for _ in range(3):
+                m.grad_sync(m._flat_grad)
+            torch.cuda.synchronize()
+            ar_ms = (time.perf_counter() - ta) / 3 * 1e3
+        res = {"value": world * b / dt, "grad_allreduce_ms": ar_ms, "grad_mb": (m._flat_grad.numel() * 4 / 1e6 if getattr(m, "_flat_grad", None) is not None else None), "unit": "train samples/s", "ms_per_step": dt * 1e3, "batch_per_gpu": b, "t_size": args.t_size,
                "steps": steps, "optimizer": "fused AdamW (both groups), clip 1.0, EMA 0.9999", "loss_finite": bool(torch.isfinite(loss)),
                "model_tflops": world * b * 3 * 159.22e9 * args.t_size / 1024.0 / dt / 1e12,
                "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
@@ -251,6 +282,18 @@ def main():
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
     elapsed = float(et.item())
     finite = bool(torch.isfinite(x).all().item())
+    gather_ms = None
+    if world > 1:  # outside the timed region: the optional final all-gather of the x0 predictions, RCCL over xGMI
+        from ddim_audio_amd import dist as ddist
+        loc = stepper.x0 if backend == "nccl" else stepper.x0.cpu()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        full = ddist.gather_batch(loc, world * B)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        assert full.size(0) == world * B
+        del full
 
     train_leg = None
     if not args.no_train_leg and os.environ.get("DDIMX_BENCH_TRAIN", "1") != "0":
@@ -278,31 +321,50 @@ def main():
             "iters_per_s": iters_per_s,
             "output_finite": finite,
         }
+        if gather_ms is not None:
+            out["final_allgather_ms"] = gather_ms  # [N*B,2,T,256] fp32 x0 predictions, untimed part of the run
         flops = 159.22e9 * T / 1024.0  # algorithmic FLOPs per sample-forward
         out["model_tflops"] = out["value"] * flops / 1e12
         if not args.no_roofline:
             with torch.no_grad():
                 rows = per_kernel_times(model, B, T)
+            ridge = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9) if args.dtype == "bf16" else MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+            mfma_peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
             for r in rows:
                 r["gbps"] = r["alg_bytes"] / r["seconds"] / 1e9
                 r["tflops"] = r["flops"] / r["seconds"] / 1e12
                 r["ms_per_fwd"] = r["seconds"] * r["launches_per_fwd"] * 1e3
+                # which roof bounds this kernel (arithmetic intensity of its ALGORITHMIC bytes vs the ridge) and how close it is
+                r["bound"] = "hbm" if r["flops"] / r["alg_bytes"] < ridge else "mfma"
+                r["frac"] = r["gbps"] / HBM_PEAK_GBS if r["bound"] == "hbm" else r["tflops"] / mfma_peak
+                r["frac_hbm"], r["frac_mfma"] = r["gbps"] / HBM_PEAK_GBS, r["tflops"] / mfma_peak
             dom = max(rows, key=lambda r: r["ms_per_fwd"])
-            ai = dom["flops"] / dom["alg_bytes"]
-            bound = "hbm" if ai < MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"
-            if bound == "hbm":
+            if dom["bound"] == "hbm":
                 out["roofline"] = {"bound": "hbm", "achieved": dom["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": dom["gbps"] / HBM_PEAK_GBS, "traffic": None}
             else:
-                out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": dom["tflops"] / MFMA_BF16_PEAK_TF, "traffic": None}
+                out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": mfma_peak, "unit": "TFLOP/s",
+                                   "frac": dom["tflops"] / mfma_peak, "traffic": None}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
             if os.path.exists(tpath):
                 tr = json.load(open(tpath))
-                if tr.get("kernel") == dom["kernel"] and tr.get("batch") == B and tr.get("t_size") == T:
-                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                per = tr.get("per_kernel", {})
+                if tr.get("batch") == B and tr.get("t_size") == T:
+                    if tr.get("kernel") == dom["kernel"]:
+                        out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                    for r in rows:  # PMC traffic of the other profiled kernels, per launch
+                        if r["kernel"] in per:
+                            r["traffic"] = per[r["kernel"]]
             out["roofline"].update(kernel=dom["kernel"], launch_us=dom["seconds"] * 1e6, alg_bytes_per_launch=dom["alg_bytes"],
-                                   launches_per_fwd=dom["launches_per_fwd"])
+                                   launches_per_fwd=dom["launches_per_fwd"],
+                                   note="isolated back-to-back launches timed with HIP events on the launch stream; inside the step the "
+                                        "same kernel runs ~10-15% faster (its input is still in the 256 MB Infinity Cache)")
+            # the per-level table the roofline discussion uses: one entry per kernel family and level
+            out["roofline"]["per_level"] = [{"kernel": r["kernel"], "level": r["level"], "bound": r["bound"], "frac": round(r["frac"], 4),
+                                             "us": round(r["seconds"] * 1e6, 2)} for r in rows]
+            for r in rows:
+                for k in [k for k in r if k.startswith("seconds")]:
+                    r[k.replace("seconds", "us")] = r.pop(k) * 1e6
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(T)

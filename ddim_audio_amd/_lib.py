@@ -49,6 +49,10 @@ _SIGS = {
                                      c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, c_void_p]),
     "ddimx_unet_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, c_void_p]),
+    "ddimx_grad_buckets": (c_int, [c_void_p, POINTER(c_longlong)]),
+    "ddimx_unet_bwd_staged": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, POINTER(c_void_p), c_int,
+                                      c_void_p]),
     "ddimx_sqerr_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     "ddimx_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_from_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -78,6 +82,14 @@ _SIGS = {
     "ddimx_conv_out_fwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "ddimx_fnet_fwd": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int,
                                c_void_p]),
+    "ddimx_downup_bwd_workspace_bytes": (c_longlong, [c_int] * 6),
+    "ddimx_downsample_bwd": (c_int, [c_int] * 3 + [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    "ddimx_upsample_add_bwd": (c_int, [c_int] * 3 + [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),
+    "ddimx_edge_bwd_workspace_floats": (c_longlong, [c_int] * 6),
+    "ddimx_conv_in_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "ddimx_conv_out_bwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
+    "ddimx_temb_fwd_train": (c_int, [c_void_p] * 11 + [c_int] * 4 + [c_void_p]),
+    "ddimx_temb_bwd": (c_int, [c_void_p] * 15 + [c_int] * 4 + [c_void_p]),
     "ddimx_fnet_mix_supported": (c_int, [c_int, c_int]),
     "ddimx_fnet_mix": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_step_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

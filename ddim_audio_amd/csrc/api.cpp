@@ -1174,8 +1174,35 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
 int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
                    long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
                    const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed, void* stream) {
+    return ddimx_unet_bwd_staged(h, packed, packed_bwd, tables, workspace, workspace_bytes, tape, tape_bytes, x, t, d_eps, grads, B, T,
+                                 dropout_p, seed, nullptr, 0, stream);
+}
+
+// Gradient buckets in the order the backward completes them (reverse execution order of the forward): the flat gradient buffer
+// is in plan order  temb | down_modules | up_modules | transformer, so the three buckets are contiguous ranges of it.
+int ddimx_grad_buckets(ddimx_handle h, long long* ranges) {
+    if (!h || !ranges) return fail("ddimx_grad_buckets: null argument");
+    long long lo[3] = {-1, -1, -1}, hi[3] = {0, 0, 0}, n = 0;
+    for (auto& p : h->specs) {
+        const long long e = n + ((p.numel + 63) & ~63ll);
+        const int b = p.name.rfind("up_modules.", 0) == 0 ? 0 : (p.name.rfind("transformer.", 0) == 0 ? 1 : 2);
+        if (lo[b] < 0) lo[b] = n;
+        hi[b] = e;
+        n = e;
+    }
+    for (int b = 0; b < 3; ++b) { ranges[2 * b] = lo[b] < 0 ? 0 : lo[b]; ranges[2 * b + 1] = lo[b] < 0 ? 0 : hi[b]; }
+    // a bucket must be one contiguous run of the plan: temb + down_modules come first, then up_modules, then transformer
+    if (!(ranges[4] == 0 && ranges[5] == ranges[0] && ranges[1] == ranges[2] && ranges[3] == n)) return fail("ddimx_grad_buckets: plan order changed");
+    return 0;
+}
+
+int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                          long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
+                          const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed,
+                          void* const* bucket_events, int n_events, void* stream) {
     if (!h || !packed || !packed_bwd || !tables || !workspace || !tape || !x || !t || !d_eps || !grads)
         return fail("ddimx_unet_bwd: null argument");
+    if (n_events != 0 && (n_events != 3 || !bucket_events)) return fail("ddimx_unet_bwd_staged: pass 0 or 3 bucket events");
     const ddimx_ctx* c = h;
     const ddimx_config& f = c->cfg;
     const int L = c->L, dt = c->dtype;
@@ -1252,6 +1279,12 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
             gy = w.Ga[l + 1];
         }
     }
+    if (n_events) {  // bucket 0: every up_modules.* gradient is final once the deferred batch sums are flushed
+        HIPCHK(colsum_multi_launch(defer, s));
+        defer.count = 0;
+        deferred_blocks = 0;
+        HIPCHK(hipEventRecord((hipEvent_t)bucket_events[0], s));
+    }
     // ---- bottleneck: up_in[L-1] = D_{L-1} + O
     const int S = T >> (L - 1), CL = f.ch[L - 1];
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
@@ -1309,6 +1342,7 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
         HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->ln0_w), 1, Fr, C5, s));
         HIPCHK(pack_perm_cols_launch(w.pgrad + width, G(c->ln0_b), 1, Fr, C5, s));
     }
+    if (n_events) HIPCHK(hipEventRecord((hipEvent_t)bucket_events[1], s));  // bucket 1: transformer.* gradients are final
     // d(D_{L-1}) = skip gradient + gradient through the bottleneck
     HIPCHK(resid_launch(dt, w.GS[L - 1], w.dTok, 1, nullptr, nullptr, w.Ga[L - 1], nullptr, B, S * Fr, CL, s));
     gy = w.Ga[L - 1];
@@ -1345,6 +1379,7 @@ int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, c
     HIPCHK(linear_bwd_w_launch(w.dh2, tp.temb_h1p, nullptr, G(c->tw[1]), G(c->tb[1]), B, 512, 512, 1, s));
     HIPCHK(linear_bwd_x_launch(w.dh2, pf(c, packed, c->tw[1]), tp.temb_h1p, w.dh1, B, 512, 512, s));
     HIPCHK(linear_bwd_w_launch(w.dh1, pf(c, packed, c->te), t, G(c->tw[0]), G(c->tb[0]), B, 512, 128, 0, s));
+    if (n_events) HIPCHK(hipEventRecord((hipEvent_t)bucket_events[2], s));  // bucket 2: temb.* and down_modules.*
     return 0;
 }
 
@@ -1514,6 +1549,95 @@ int ddimx_fnet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
     const int S = T >> (L - 1);
     CHK(run_fnet(c, packed, tables, w, x, B, S, s));
     HIPCHK(hipMemcpyAsync(out, w.O, (size_t)B * S * c->width * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ---- backward twins of the per-op forwards (the whole-network backward runs exactly these launches) ---------------------
+struct DuBwdWs { float *partial, *stats, *dgb; size_t total; };
+static void carve_du_bwd(char* base, int dtype, int Cs, int Cb, int B, int Hs, int Ws, DuBwdWs* o) {
+    // Cs/Hs/Ws: the SMALL (low-resolution) side, Cb the big side's channels; the bias gradient sums run over whichever side
+    // carries the bias (Downsample: small side, Upsample: big side), so size for the larger of the two
+    Carver cv{base, 0};
+    o->partial = (float*)cv.take(wgrad_partial_floats(dtype, DOWN4, Cb, Cs, B, Hs, Ws) * 4);
+    const size_t s_small = (size_t)B * resid_nparts(dtype, Hs * Ws, Cs) * Cs * 2;
+    const size_t s_big = (size_t)B * resid_nparts(dtype, 4 * Hs * Ws, Cb) * Cb * 2;
+    o->stats = (float*)cv.take((s_small > s_big ? s_small : s_big) * 4);
+    o->dgb = (float*)cv.take((size_t)B * (Cs > Cb ? Cs : Cb) * 4);
+    o->total = cv.off;
+}
+static int op_channel_sums(int dt, const void* x, const DuBwdWs& w, float* dst, int B, int HW, int C, hipStream_t s) {
+    HIPCHK(tensor_stats_launch(dt, x, w.stats, B, HW, C, s));
+    HIPCHK(partsum_launch(w.stats, B, resid_nparts(dt, HW, C), C, w.dgb, C, s, 2));
+    HIPCHK(colsum_launch(w.dgb, B, C, C, dst, s));
+    return 0;
+}
+long long ddimx_downup_bwd_workspace_bytes(int dtype, int Csmall, int Cbig, int B, int Hsmall, int Wsmall) {
+    DuBwdWs o;
+    carve_du_bwd(nullptr, dtype, Csmall, Cbig, B, Hsmall, Wsmall, &o);
+    return (long long)o.total;
+}
+int ddimx_downsample_bwd(int dtype, int Cin, int Cout, const void* x, const void* dy, const void* w_dgrad, const void* dx_add, void* dx,
+                         float* d_w, float* d_b, void* workspace, int B, int H, int W, void* stream) {
+    if (!x || !dy || !w_dgrad || !dx || !d_w || !d_b || !workspace) return fail("ddimx_downsample_bwd: null argument");
+    if ((H | W) & 1) return fail("ddimx_downsample_bwd: H, W must be even (got %d x %d)", H, W);
+    hipStream_t s = (hipStream_t)stream;
+    DuBwdWs o;
+    carve_du_bwd((char*)workspace, dtype, Cout, Cin, B, H / 2, W / 2, &o);
+    CHK(run_wgrad(dtype, DOWN4, Cin, Cout, x, dy, nullptr, nullptr, XF_NONE, o.partial, d_w, B, H / 2, W / 2, s));
+    CHK(op_channel_sums(dtype, dy, o, d_b, B, (H / 2) * (W / 2), Cout, s));
+    ConvCall u = {dtype, UP4, Cout, Cin, dy, w_dgrad, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, dx_add, dx, nullptr, B, H / 2, W / 2};
+    u.batch_plan = true;
+    return run_conv(u, s, nullptr, nullptr);
+}
+int ddimx_upsample_add_bwd(int dtype, int Cin, int Cout, const void* x, const void* dy, const void* w_dgrad, void* dx, float* d_w,
+                           float* d_b, void* workspace, int B, int H, int W, void* stream) {
+    if (!x || !dy || !w_dgrad || !dx || !d_w || !d_b || !workspace) return fail("ddimx_upsample_add_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DuBwdWs o;
+    carve_du_bwd((char*)workspace, dtype, Cin, Cout, B, H, W, &o);
+    // ConvTranspose2d weight [Cin][Cout][4][4]: its gradient is the stride-2 weight gradient with the roles of input and output
+    // swapped (the big tensor dy plays the halo operand, the small tensor x the output gradient)
+    CHK(run_wgrad(dtype, DOWN4, Cout, Cin, dy, x, nullptr, nullptr, XF_NONE, o.partial, d_w, B, H, W, s));
+    CHK(op_channel_sums(dtype, dy, o, d_b, B, 4 * H * W, Cout, s));
+    ConvCall d = {dtype, DOWN4, Cout, Cin, dy, w_dgrad, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, dx, nullptr, B, 2 * H, 2 * W};
+    d.batch_plan = true;
+    return run_conv(d, s, nullptr, nullptr);
+}
+long long ddimx_edge_bwd_workspace_floats(int dtype, int B, int C0, int Cio, int H, int W) {
+    return (long long)edge_wgrad_partial_floats(dtype, B, C0, Cio, H, W);
+}
+int ddimx_conv_in_bwd(int dtype, const void* dy, const float* x, float* partial, float* d_w, float* d_b, int B, int Cin, int C0, int H,
+                      int W, void* stream) {
+    if (!dy || !x || !partial || !d_w || !d_b) return fail("ddimx_conv_in_bwd: null argument");
+    HIPCHK(edge_wgrad_launch(dtype, 0, dy, nullptr, x, partial, d_w, d_b, B, C0, Cin, H, W, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_conv_out_bwd(int dtype, const float* d_eps, const void* a, const void* b, const float* w_packed, void* d_sum, float* partial,
+                       float* d_w, float* d_b, int B, int C0, int Cout, int H, int W, void* stream) {
+    if (!d_eps || !a || !b || !w_packed || !d_sum || !partial || !d_w || !d_b) return fail("ddimx_conv_out_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(conv_out_bwd_data_launch(dtype, d_eps, w_packed, d_sum, B, C0, Cout, H, W, s));
+    HIPCHK(edge_wgrad_launch(dtype, 1, a, b, d_eps, partial, d_w, d_b, B, C0, Cout, H, W, s));
+    return 0;
+}
+int ddimx_temb_fwd_train(const float* te, const int64_t* t, const float* w0, const float* b0, const float* w1, const float* b1,
+                         const float* w2, const float* b2, float* h1_pre, float* h2_pre, float* out, int B, int pos_ch, int emb_ch, int E,
+                         void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(linear_rows_launch(te, t, w0, b0, h1_pre, B, emb_ch, pos_ch, 0, s));
+    HIPCHK(linear_rows_launch(h1_pre, nullptr, w1, b1, h2_pre, B, emb_ch, emb_ch, 0, s, 1));
+    HIPCHK(linear_rows_launch(h2_pre, nullptr, w2, b2, out, B, E, emb_ch, 0, s, 1));
+    return 0;
+}
+int ddimx_temb_bwd(const float* d_out, const float* te, const int64_t* t, const float* w1, const float* w2, const float* h1_pre,
+                   const float* h2_pre, float* d_h2, float* d_h1, float* d_w0, float* d_b0, float* d_w1, float* d_b1, float* d_w2,
+                   float* d_b2, int B, int pos_ch, int emb_ch, int E, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(linear_bwd_w_launch(d_out, h2_pre, nullptr, d_w2, d_b2, B, E, emb_ch, 1, s));
+    HIPCHK(linear_bwd_x_launch(d_out, w2, h2_pre, d_h2, B, E, emb_ch, s));
+    HIPCHK(linear_bwd_w_launch(d_h2, h1_pre, nullptr, d_w1, d_b1, B, emb_ch, emb_ch, 1, s));
+    HIPCHK(linear_bwd_x_launch(d_h2, w1, h1_pre, d_h1, B, emb_ch, emb_ch, s));
+    HIPCHK(linear_bwd_w_launch(d_h1, te, t, d_w0, d_b0, B, emb_ch, pos_ch, 0, s));
     return 0;
 }
 

@@ -42,27 +42,61 @@ def sample_sharded(x_full, sampler, gather=True, group=None):
     return gather_batch(local, n, group) if gather else local
 
 
-def make_grad_sync(group=None, bucket_mb=64):
+def make_grad_sync(group=None, bucket_mb=64, overlap=True):
     """Data-parallel gradient averaging for the training step: the backward writes every parameter
-    gradient into ONE flat fp32 buffer (47.2 M elements = 188.6 MB for configs/audio.yml), which is all-reduced here in
-    ``bucket_mb`` slices issued back to back (RCCL pipelines them over the xGMI links) and scaled by 1/world.  The local
-    loss is a batch mean (functions/losses.py:18), so sum/world of the rank gradients is the global-batch gradient."""
+    gradient into ONE flat fp32 buffer (47.2 M elements = 188.6 MB for configs/audio.yml).  ``sync(flat)`` all-reduces it in
+    ``bucket_mb`` slices issued back to back (RCCL pipelines them over the xGMI links) and scales by 1/world.  With
+    ``overlap`` (RCCL / ``nccl`` backend) the backward instead hands over three buckets in the order it finishes them -- the up
+    path (34 MB), the FNet bottleneck (109 MB), then the down path + timestep MLP (45 MB) -- each behind a HIP event, and
+    ``sync.staged`` issues each bucket's all-reduce on a side stream once its event has fired: only the last bucket's
+    collective is exposed.  The local loss is a batch mean (functions/losses.py:18), so sum/world of the rank gradients is
+    the global-batch gradient."""
+    state = {"side": None}
+
+    def _slices(flat, lo, hi):
+        n = max(1, (bucket_mb << 20) // flat.element_size())
+        return [flat[i:min(i + n, hi)] for i in range(lo, hi, n)]
+
+    def active():
+        return (overlap and dist.is_initialized() and dist.get_world_size(group) > 1 and dist.get_backend(group) == "nccl")
+
     def sync(flat):
         if not dist.is_initialized():
             return flat
         world = dist.get_world_size(group)
         if world == 1:
             return flat
-        n = max(1, (bucket_mb << 20) // flat.element_size())
-        works = [dist.all_reduce(flat[i:i + n], op=dist.ReduceOp.SUM, group=group, async_op=True) for i in range(0, flat.numel(), n)]
+        works = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v in _slices(flat, 0, flat.numel())]
         for w in works:
             w.wait()
         flat.mul_(1.0 / world)
         return flat
+
+    def staged(flat, ranges, events):
+        """ranges: [(begin, end)] float offsets per bucket in readiness order; events: the torch.cuda.Event the backward records
+        when the bucket is final.  Returns after making the CURRENT stream wait for every collective."""
+        world = dist.get_world_size(group)
+        if state["side"] is None:
+            state["side"] = torch.cuda.Stream(device=flat.device)
+        side = state["side"]
+        works = []
+        for (lo, hi), ev in zip(ranges, events):
+            if hi <= lo:
+                continue
+            side.wait_event(ev)
+            with torch.cuda.stream(side):  # the collective is ordered behind `side`, i.e. behind the bucket's event
+                works += [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v in _slices(flat, lo, hi)]
+        for w in works:
+            w.wait()                       # current stream waits for the RCCL stream
+        flat.mul_(1.0 / world)
+        return flat
+
+    sync.staged = staged
+    sync.active = active
     return sync
 
 
-def attach_grad_sync(model, group=None, bucket_mb=64):
+def attach_grad_sync(model, group=None, bucket_mb=64, overlap=True):
     """Make ``model``'s backward average its gradients over the ranks of ``group`` (one process per GPU)."""
-    model.grad_sync = make_grad_sync(group, bucket_mb)
+    model.grad_sync = make_grad_sync(group, bucket_mb, overlap)
     return model

@@ -247,12 +247,32 @@ class _UNetTrainFn(torch.autograd.Function):
             ws = model._train_ws
             tb = _lib.DdimxTables(ctx.tables[0].data_ptr(), ctx.tables[1].data_ptr(), ctx.tables[2].data_ptr())
             g = d_eps.contiguous()
-            _lib.check(lib.ddimx_unet_bwd(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb), _lib.ptr(ws),
-                                          ws.numel(), _lib.ptr(ctx.tape), ctx.tape.numel(), _lib.ptr(x), _lib.ptr(ctx.t), _lib.ptr(g),
-                                          _lib.ptr(flat), b, t_len, ctx.p, ctx.seed, _lib.stream()))
             sync = getattr(model, "grad_sync", None)
-            if sync is not None:
-                sync(flat)  # data parallel: average the whole gradient buffer over ranks (one RCCL all-reduce)
+            staged = getattr(sync, "staged", None) if sync is not None else None
+            if staged is not None and sync.active():
+                # data parallel with overlap: the backward records an event per gradient bucket (up path, bottleneck, the rest)
+                # and each bucket's all-reduce is issued on a side stream as soon as its event has fired, while the remaining
+                # backward kernels keep running on this stream
+                evs = getattr(model, "_bucket_events", None)
+                if evs is None:
+                    evs = [torch.cuda.Event() for _ in range(3)]
+                    for e in evs:
+                        e.record()  # torch creates the hipEvent lazily: force it, the library re-records it
+                    model._bucket_events = evs
+                rng = (ctypes.c_longlong * 6)()
+                _lib.check(lib.ddimx_grad_buckets(model._handle, rng))
+                arr = (ctypes.c_void_p * 3)(*[e.cuda_event for e in evs])
+                _lib.check(lib.ddimx_unet_bwd_staged(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb),
+                                                     _lib.ptr(ws), ws.numel(), _lib.ptr(ctx.tape), ctx.tape.numel(), _lib.ptr(x),
+                                                     _lib.ptr(ctx.t), _lib.ptr(g), _lib.ptr(flat), b, t_len, ctx.p, ctx.seed, arr, 3,
+                                                     _lib.stream()))
+                staged(flat, [(rng[2 * i], rng[2 * i + 1]) for i in range(3)], evs)
+            else:
+                _lib.check(lib.ddimx_unet_bwd(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb), _lib.ptr(ws),
+                                              ws.numel(), _lib.ptr(ctx.tape), ctx.tape.numel(), _lib.ptr(x), _lib.ptr(ctx.t), _lib.ptr(g),
+                                              _lib.ptr(flat), b, t_len, ctx.p, ctx.seed, _lib.stream()))
+                if sync is not None:
+                    sync(flat)  # data parallel: average the whole gradient buffer over ranks
         ctx.tape = None
         return (None, None, None, None) + tuple(flat[o:o + n].view(shape) for o, n, shape in layout)
 

@@ -125,6 +125,17 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
 int ddimx_unet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
                    long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
                    const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed, void* stream);
+/* Data-parallel training (the reference has no counterpart: runners/diffusion.py:216 is a commented DataParallel):
+ * the same backward, which additionally records three caller-owned hipEvent_t on `stream` as soon as a bucket of the flat
+ * gradient buffer is final -- bucket 0 = up_modules.* (ready after the up path), 1 = transformer.* (after the bottleneck),
+ * 2 = temb.* + down_modules.* (at the end) -- so that the caller can all-reduce each bucket on a second stream while the rest of
+ * the backward still runs.  ddimx_grad_buckets fills ranges[6] = {begin0, end0, begin1, end1, begin2, end2} (float offsets into
+ * the flat gradient buffer, each bucket one contiguous run).  n_events must be 0 (plain ddimx_unet_bwd) or 3. */
+int ddimx_grad_buckets(ddimx_handle h, long long* ranges);
+int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                          long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
+                          const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed,
+                          void* const* bucket_events, int n_events, void* stream);
 /* backward of the per-sample squared-error loss (functions/losses.py:18): d_out[b] = 2 g[b] (out[b] - e[b]) */
 int ddimx_sqerr_loss_bwd(const float* e, const float* out, const float* g_per_sample, float* d_out, int B,
                          long long per_sample, void* stream);
@@ -211,6 +222,37 @@ int ddimx_conv_out_fwd(int dtype, const void* a, const void* b, const float* w_p
  * order f*C_last + c (the reference's is c*Fr + f: models/diffusion.py:273-278).  workspace: ddimx_workspace_bytes(B, T). */
 int ddimx_fnet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
                    const void* x, float* out, int B, int T, void* stream);
+
+/* ---- backward twins of the per-op forwards (autograd of the reference modules; gradients are WRITTEN, fp32, in the
+ * parameter's own layout).  The whole-network ddimx_unet_bwd issues exactly these launches. -------------------------------
+ * Downsample (models/diffusion.py:70-78): x [B][H][W][Cin] the forward input, dy [B][H/2][W/2][Cout]; w_dgrad = the SAME weight
+ * tensor packed with ddimx_pack_convT(dtype, w, .., I = Cout, O = Cin) (the data gradient of a stride-2 conv is the sub-pixel
+ * transposed conv); dx = dx_add (nullable, same shape) + d(input).  workspace: ddimx_downup_bwd_workspace_bytes(dtype, Cout, Cin,
+ * B, H/2, W/2) bytes. */
+long long ddimx_downup_bwd_workspace_bytes(int dtype, int Csmall, int Cbig, int B, int Hsmall, int Wsmall);
+int ddimx_downsample_bwd(int dtype, int Cin, int Cout, const void* x, const void* dy, const void* w_dgrad, const void* dx_add, void* dx,
+                         float* d_w, float* d_b, void* workspace, int B, int H, int W, void* stream);
+/* Upsample + skip add (models/diffusion.py:59-67,284): x [B][H][W][Cin] the forward input, dy [B][2H][2W][Cout] (also the
+ * gradient of the skip tensor, unchanged); w_dgrad = the ConvTranspose2d weight packed with ddimx_pack_conv(dtype, w, .., O = Cin,
+ * I = Cout, 4, 4).  d_w in the ConvTranspose2d layout [Cin][Cout][4][4].  workspace: (dtype, Cin, Cout, B, H, W). */
+int ddimx_upsample_add_bwd(int dtype, int Cin, int Cout, const void* x, const void* dy, const void* w_dgrad, void* dx, float* d_w,
+                           float* d_b, void* workspace, int B, int H, int W, void* stream);
+/* Edge convolutions (models/diffusion.py:189-208).  conv_in: dy NHWC gradient of its output, x the NCHW fp32 network input.
+ * conv_out: d_sum = gradient w.r.t. (a + b) NHWC (it is the gradient of both summands); weight / bias gradients from a + b.
+ * partial: ddimx_edge_bwd_workspace_floats() floats. */
+long long ddimx_edge_bwd_workspace_floats(int dtype, int B, int C0, int Cio, int H, int W);
+int ddimx_conv_in_bwd(int dtype, const void* dy, const float* x, float* partial, float* d_w, float* d_b, int B, int Cin, int C0, int H,
+                      int W, void* stream);
+int ddimx_conv_out_bwd(int dtype, const float* d_eps, const void* a, const void* b, const float* w_packed, void* d_sum, float* partial,
+                       float* d_w, float* d_b, int B, int C0, int Cout, int H, int W, void* stream);
+/* BetaEmbedding (models/diffusion.py:110-120), training: the forward keeps the two pre-activations ([B][emb_ch] each), the backward
+ * returns every weight / bias gradient (d_h2, d_h1: [B][emb_ch] scratch). */
+int ddimx_temb_fwd_train(const float* te, const int64_t* t, const float* w0, const float* b0, const float* w1, const float* b1,
+                         const float* w2, const float* b2, float* h1_pre, float* h2_pre, float* out, int B, int pos_ch, int emb_ch, int E,
+                         void* stream);
+int ddimx_temb_bwd(const float* d_out, const float* te, const int64_t* t, const float* w1, const float* w2, const float* h1_pre,
+                   const float* h2_pre, float* d_h2, float* d_h1, float* d_w0, float* d_b0, float* d_w1, float* d_b1, float* d_w2,
+                   float* d_b2, int B, int pos_ch, int emb_ch, int E, void* stream);
 
 /* ---- sampler (functions/denoising.py:10-52) ------------------------------------------------------- */
 /* coef [n_iter][6] fp32 rows (t, sqrt(1-at), sqrt(at), sqrt(at_next), c2, c1); step: device int counter.

@@ -430,3 +430,48 @@ def test_training_resume_is_bit_exact(tmp_path):
         assert torch.equal(st.ema_helper.shadow[n], st2.ema_helper.shadow[n]), n
     for k in st.optimizers:
         assert st.optimizers[k].param_groups[0]["lr"] == st2.optimizers[k].param_groups[0]["lr"]
+
+
+def test_staged_backward_buckets_are_final_when_their_event_fires():
+    """ddimx_unet_bwd_staged (data-parallel overlap): the three gradient buckets -- up_modules.*, transformer.*,
+    temb.* + down_modules.* -- must be complete when their HIP event fires, because the all-reduce of a bucket starts then,
+    while the rest of the backward is still running.  A stand-in ``grad_sync`` snapshots each bucket on a side stream behind
+    its event; the snapshots must equal the final buffer, the result must equal the plain backward bit for bit, and the
+    ranges must tile the flat buffer by parameter name."""
+    cfg, m = _train_model("torch.cuda.BFloat16Tensor")
+    alphas = make_schedule(cfg.diffusion)[1].cuda()
+    shape = (4, 2, 256, 256)
+    x0, e = synth.gaussian("staged.x0", shape).cuda(), synth.gaussian("staged.e", shape).cuda()
+    t = torch.tensor([5, 994, 300, 650]).cuda()
+    losses.noise_estimation_loss(m, x0, t, e, alphas).backward()
+    plain = m._flat_grad.clone()
+    m.zero_grad(set_to_none=True)
+    seen = {}
+
+    def staged(flat, ranges, events):
+        side = torch.cuda.Stream()
+        seen["ranges"] = ranges
+        seen["snaps"] = []
+        for (lo, hi), ev in zip(ranges, events):
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                seen["snaps"].append(flat[lo:hi].clone())
+        torch.cuda.current_stream().wait_stream(side)
+        return flat
+
+    sync = lambda flat: flat  # noqa: E731
+    sync.staged, sync.active = staged, (lambda: True)
+    m.grad_sync = sync
+    losses.noise_estimation_loss(m, x0, t, e, alphas).backward()
+    torch.cuda.synchronize()
+    flat = m._flat_grad
+    assert torch.equal(flat, plain), "the staged backward must compute the same gradients"
+    (a0, b0), (a1, b1), (a2, b2) = seen["ranges"]
+    assert a2 == 0 and b2 == a0 and b0 == a1 and b1 == flat.numel()
+    for snap, (lo, hi) in zip(seen["snaps"], seen["ranges"]):
+        assert torch.equal(snap, flat[lo:hi]), "a bucket changed after its event fired"
+    total, layout = m._grad_layout(__import__("ddim_audio_amd")._lib.load())
+    for (name, _), (off, numel, _) in zip(m.named_parameters(), layout):
+        b = 0 if name.startswith("up_modules.") else (1 if name.startswith("transformer.") else 2)
+        lo, hi = seen["ranges"][b]
+        assert lo <= off and off + numel <= hi, name

@@ -291,3 +291,117 @@ def test_training_reduces_the_loss_and_state_dicts_roundtrip():
         o.load_state_dict(sd[k])
     loss_after, _ = train.train_step(m, x, state, alphas, e=e, t=t)
     assert np.isfinite(float(loss_after))
+
+
+# ---- backward twins of the remaining per-op forwards ("_bwd twin of each forward op") ---------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("cin,cout,hw,b", [(32, 64, (36, 44), 2), (96, 128, (18, 22), 2), (192, 256, (12, 20), 1)])
+def test_downsample_upsample_backward_vs_oracle(dt, cin, cout, hw, b):
+    """ddimx_downsample_bwd / ddimx_upsample_add_bwd against autograd through the oracle's Downsample / Upsample
+    (models/diffusion.py:59-78): input gradients (incl. the accumulated skip gradient), weight and bias gradients."""
+    lib = _lib.load()
+    tdt = G.TORCH_DT[dt]
+    sd = synth.fill_state_dict({"d.conv.weight": torch.empty(cout, cin, 4, 4), "d.conv.bias": torch.empty(cout),
+                                "u.conv.weight": torch.empty(cout, cin, 4, 4), "u.conv.bias": torch.empty(cin)})
+    h, w = hw
+    # ---- Downsample
+    x = synth.gaussian(f"dbw{cin}.x", (b, cin, h, w))
+    dy = synth.gaussian(f"dbw{cin}.dy", (b, cout, h // 2, w // 2))
+    extra = synth.gaussian(f"dbw{cin}.extra", (b, cin, h, w)) * 0.5
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref_cpu.downsample(leaf, "d.", xr).backward(dy)
+    xn, dyn, exn = G.to_nhwc(x, dt), G.to_nhwc(dy, dt), G.to_nhwc(extra, dt)
+    dxn = torch.empty_like(xn)
+    wdg = G.g(sd["d.conv.weight"])
+    wd_dgrad = torch.empty(2 * 6 * 2 * cin * cout, dtype=tdt, device=G.dev())
+    _lib.check(lib.ddimx_pack_convT(dt, _lib.ptr(wdg), _lib.ptr(wd_dgrad), cout, cin, _lib.stream()))
+    d_w, d_b = torch.full((cout, cin, 4, 4), float("nan"), device=G.dev()), torch.full((cout,), float("nan"), device=G.dev())
+    ws = torch.empty(int(lib.ddimx_downup_bwd_workspace_bytes(dt, cout, cin, b, h // 2, w // 2)), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.ddimx_downsample_bwd(dt, cin, cout, _lib.ptr(xn), _lib.ptr(dyn), _lib.ptr(wd_dgrad), _lib.ptr(exn), _lib.ptr(dxn),
+                                        _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), b, h, w, _lib.stream()))
+    ex_r = G.from_nhwc(exn, dt)
+    G.check_close(G.from_nhwc(dxn, dt), xr.grad + ex_r, dt, f"downsample dx {cin}->{cout}")
+    G.check_close(d_w.cpu(), leaf["d.conv.weight"].grad, dt, "downsample dW", scale=4.0)
+    G.check_close(d_b.cpu(), leaf["d.conv.bias"].grad, dt, "downsample db", scale=4.0)
+    # ---- Upsample (+ skip add: the skip's gradient is dy itself)
+    xu = synth.gaussian(f"ubw{cout}.x", (b, cout, h // 2, w // 2))
+    dyu = synth.gaussian(f"ubw{cout}.dy", (b, cin, h, w))
+    xur = xu.clone().requires_grad_(True)
+    ref_cpu.upsample(leaf, "u.", xur).backward(dyu)
+    xun, dyun = G.to_nhwc(xu, dt), G.to_nhwc(dyu, dt)
+    dxun = torch.empty_like(xun)
+    wu_dgrad = G.pack_conv(sd["u.conv.weight"], dt)  # [O = cout(Cin of the upsample)][I = cin][4][4] read as a Conv2d weight
+    du_w, du_b = torch.full((cout, cin, 4, 4), float("nan"), device=G.dev()), torch.full((cin,), float("nan"), device=G.dev())
+    ws = torch.empty(int(lib.ddimx_downup_bwd_workspace_bytes(dt, cout, cin, b, h // 2, w // 2)), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.ddimx_upsample_add_bwd(dt, cout, cin, _lib.ptr(xun), _lib.ptr(dyun), _lib.ptr(wu_dgrad), _lib.ptr(dxun), _lib.ptr(du_w),
+                                          _lib.ptr(du_b), _lib.ptr(ws), b, h // 2, w // 2, _lib.stream()))
+    G.check_close(G.from_nhwc(dxun, dt), xur.grad, dt, f"upsample dx {cout}->{cin}")
+    G.check_close(du_w.cpu(), leaf["u.conv.weight"].grad, dt, "upsample dW", scale=4.0)
+    G.check_close(du_b.cpu(), leaf["u.conv.bias"].grad, dt, "upsample db", scale=4.0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_edge_conv_backward_vs_oracle(dt):
+    """ddimx_conv_in_bwd / ddimx_conv_out_bwd against autograd of Conv2d(2->32) and Conv2d(32->2) on `x + hidden[0]`
+    (models/diffusion.py:189-208,283-292)."""
+    lib = _lib.load()
+    b, h, w, c0, cio = 2, 40, 256, 32, 2
+    sd = synth.fill_state_dict({"ci.weight": torch.empty(c0, cio, 3, 3), "ci.bias": torch.empty(c0),
+                                "co.weight": torch.empty(cio, c0, 3, 3), "co.bias": torch.empty(cio)})
+    x = synth.gaussian("ebw.x", (b, cio, h, w))
+    dy = synth.gaussian("ebw.dy", (b, c0, h, w))
+    wr, br = sd["ci.weight"].clone().requires_grad_(True), sd["ci.bias"].clone().requires_grad_(True)
+    dyn = G.to_nhwc(dy, dt)
+    torch.nn.functional.conv2d(x, wr, br, padding=1).backward(G.from_nhwc(dyn, dt))
+    part = torch.empty(int(lib.ddimx_edge_bwd_workspace_floats(dt, b, c0, cio, h, w)), device=G.dev())
+    d_w, d_b = torch.full((c0, cio, 3, 3), float("nan"), device=G.dev()), torch.full((c0,), float("nan"), device=G.dev())
+    xg = G.g(x)
+    _lib.check(lib.ddimx_conv_in_bwd(dt, _lib.ptr(dyn), _lib.ptr(xg), _lib.ptr(part), _lib.ptr(d_w), _lib.ptr(d_b), b, cio, c0, h, w, _lib.stream()))
+    G.check_close(d_w.cpu(), wr.grad, G.F32, "conv_in dW", scale=4.0)
+    G.check_close(d_b.cpu(), br.grad, G.F32, "conv_in db", scale=4.0)
+    # output conv
+    a, s2 = synth.gaussian("ebw.a", (b, c0, h, w)), synth.gaussian("ebw.s", (b, c0, h, w)) * 0.7
+    d_eps = synth.gaussian("ebw.de", (b, cio, h, w))
+    an, sn = G.to_nhwc(a, dt), G.to_nhwc(s2, dt)
+    ssum = (G.from_nhwc(an, dt) + G.from_nhwc(sn, dt)).requires_grad_(True)
+    wo, bo = sd["co.weight"].clone().requires_grad_(True), sd["co.bias"].clone().requires_grad_(True)
+    torch.nn.functional.conv2d(ssum, wo, bo, padding=1).backward(d_eps)
+    wp = G.pack_conv(sd["co.weight"], G.F32)
+    dsn = torch.empty_like(an)
+    d_wo, d_bo = torch.full((cio, c0, 3, 3), float("nan"), device=G.dev()), torch.full((cio,), float("nan"), device=G.dev())
+    deg = G.g(d_eps)
+    _lib.check(lib.ddimx_conv_out_bwd(dt, _lib.ptr(deg), _lib.ptr(an), _lib.ptr(sn), _lib.ptr(wp), _lib.ptr(dsn), _lib.ptr(part), _lib.ptr(d_wo),
+                                      _lib.ptr(d_bo), b, c0, cio, h, w, _lib.stream()))
+    G.check_close(G.from_nhwc(dsn, dt), ssum.grad, dt, "conv_out d(a+b)")
+    G.check_close(d_wo.cpu(), wo.grad, G.F32 if dt == G.F32 else G.BF16, "conv_out dW", scale=4.0)
+    G.check_close(d_bo.cpu(), bo.grad, G.F32, "conv_out db", scale=4.0)
+
+
+def test_temb_backward_vs_oracle():
+    """ddimx_temb_fwd_train / ddimx_temb_bwd against autograd of BetaEmbedding (models/diffusion.py:110-120)."""
+    lib = _lib.load()
+    shapes = {"temb.weight.0.weight": (512, 128), "temb.weight.0.bias": (512,), "temb.weight.1.weight": (512, 512),
+              "temb.weight.1.bias": (512,), "temb.weight.2.weight": (4416, 512), "temb.weight.2.bias": (4416,)}
+    sd = synth.fill_state_dict({k: torch.empty(s) for k, s in shapes.items()})
+    sd["temb.te"] = ref_cpu.timestep_table(1000)
+    t = torch.tensor([0, 999, 123, 500, 7])
+    d_out = synth.gaussian("tbw.dout", (5, 4416))
+    leaf = {k: (v.clone().requires_grad_(True) if k != "temb.te" else v) for k, v in sd.items()}
+    out_ref = ref_cpu.beta_embedding(leaf, t)
+    out_ref.backward(d_out)
+    te, tg = G.g(sd["temb.te"]), t.to(G.dev())
+    ws = [G.g(sd[f"temb.weight.{i}.{k}"]) for i in range(3) for k in ("weight", "bias")]
+    h1, h2 = torch.empty(5, 512, device=G.dev()), torch.empty(5, 512, device=G.dev())
+    out = torch.empty(5, 4416, device=G.dev())
+    _lib.check(lib.ddimx_temb_fwd_train(_lib.ptr(te), _lib.ptr(tg), *[_lib.ptr(v) for v in ws], _lib.ptr(h1), _lib.ptr(h2), _lib.ptr(out),
+                                        5, 128, 512, 4416, _lib.stream()))
+    G.check_close(out.cpu(), out_ref.detach(), G.F32, "temb forward (training)")
+    grads = [torch.full_like(v, float("nan")) for v in ws]
+    dh2, dh1 = torch.empty(5, 512, device=G.dev()), torch.empty(5, 512, device=G.dev())
+    dg = G.g(d_out)
+    _lib.check(lib.ddimx_temb_bwd(_lib.ptr(dg), _lib.ptr(te), _lib.ptr(tg), _lib.ptr(ws[2]), _lib.ptr(ws[4]), _lib.ptr(h1), _lib.ptr(h2),
+                                  _lib.ptr(dh2), _lib.ptr(dh1), *[_lib.ptr(v) for v in grads], 5, 128, 512, 4416, _lib.stream()))
+    for i in range(3):
+        for j, k in enumerate(("weight", "bias")):
+            G.check_close(grads[2 * i + j].cpu(), leaf[f"temb.weight.{i}.{k}"].grad, G.F32, f"temb d{k}{i}", scale=4.0)
