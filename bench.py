@@ -114,9 +114,10 @@ def per_kernel_times(model, B, T, reps=20):
     return rows
 
 
-def cpu_baseline(T, iters=3, batch=2):
-    """The CPU oracle (plain PyTorch fp32 restatement, pinned to the reference by golden vectors) on the
-    host cores: ``iters`` DDIM iterations at batch ``batch`` after one small warm-up."""
+def cpu_baseline(T, B, iters=2):
+    """The CPU oracle (plain PyTorch fp32 restatement, pinned to the reference by golden vectors) on the host cores:
+    ``iters`` DDIM iterations of the SAME workload (batch B, length T) after one small warm-up, plus -- as ``cfg1`` -- one
+    iteration at BASELINE configs[0]'s shape (num_samples = 1, sampling.t_size = 8192: the reference's own CPU-runnable case)."""
     from ddim_audio_amd import configs, schedule, synth
     from ddim_audio_amd.model import state_inventory
     from oracle import ref_cpu
@@ -128,15 +129,22 @@ def cpu_baseline(T, iters=3, batch=2):
     cores = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
     torch.set_num_threads(cores)
     fn = lambda a, b: ref_cpu.model_forward(sd, cfg, a, b)  # noqa: E731
-    with torch.no_grad():
-        ref_cpu.model_forward(sd, cfg, torch.randn(1, 2, 64, 256), torch.tensor([10]))  # warm-up
-        x = torch.randn(batch, 2, T, 256)
-        seq = [int(v) for v in torch.linspace(0, 999, iters).tolist()]
+
+    def leg(batch, t_len, n):
+        x = torch.randn(batch, 2, t_len, 256)
+        seq = [int(v) for v in torch.linspace(0, 999, n).tolist()]
         t0 = time.perf_counter()
         ref_cpu.generalized_steps(x, seq, fn, alphas, [-1], eta=0.0)
-        dt = time.perf_counter() - t0
-    return dict(value=batch * iters / dt, unit="sample-fwd/s", cores=cores, kind="port",
-                sample=f"{iters} DDIM iterations x batch {batch} at T={T} (oracle/ref_cpu.py, fp32, {cores} threads), {dt:.1f} s")
+        return time.perf_counter() - t0
+
+    with torch.no_grad():
+        ref_cpu.model_forward(sd, cfg, torch.randn(1, 2, 64, 256), torch.tensor([10]))  # warm-up
+        dt = leg(B, T, iters)
+        dt1 = leg(1, 8192, 1)
+    return dict(value=B * iters / dt, unit="sample-fwd/s", cores=cores, kind="port",
+                sample=f"{iters} DDIM iterations x batch {B} at T={T} (oracle/ref_cpu.py, fp32, {cores} threads), {dt:.1f} s",
+                cfg1=dict(value=1.0 / dt1, unit="sample-fwd/s", t1024_equivalents_per_s=8.0 / dt1,
+                          sample=f"1 DDIM iteration x batch 1 at T=8192 (BASELINE configs[0] shape), {dt1:.1f} s"))
 
 
 def training_leg(args, cfg, dev, rank, world, backend, steps=3):
@@ -200,6 +208,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="spectrograms per GPU (weak scaling)")
     ap.add_argument("--t-size", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--fnet-dtype", default=None, choices=["bf16", "f32"],
+                    help="model.transformers.dtype: operand type of the FNet's dense GEMMs (default: same as --dtype; f32 with "
+                         "--dtype bf16 is the reference's mixed mode, models/diffusion.py:242-246)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
@@ -246,7 +257,8 @@ def main():
 
     B, T = args.batch, args.t_size
     tstr = "torch.cuda.BFloat16Tensor" if args.dtype == "bf16" else "torch.cuda.FloatTensor"
-    cfg = configs.audio_config(tstr)
+    fstr = None if args.fnet_dtype is None else ("torch.cuda.BFloat16Tensor" if args.fnet_dtype == "bf16" else "torch.cuda.FloatTensor")
+    cfg = configs.audio_config(tstr, fstr)
     model = synth.fill_module(D.Model(cfg)).eval()
     alphas = schedule.make_schedule(cfg.diffusion)[1]
     n_sched = cfg.diffusion.num_diffusion_timesteps
@@ -316,7 +328,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: batch {B}/GPU x [2,{T},256] spectrograms, audio.yml U-Net (47.2M params, "
-                                   f"hash-filled weights), generalized_steps eta=0 over the 1000-step schedule, hipGraph replay",
+                                   f"hash-filled weights; FNet GEMM operands {args.fnet_dtype or args.dtype}), generalized_steps eta=0 over the 1000-step "
+                                   f"schedule, hipGraph replay of {len(stepper.bounds)} batch shard(s) on parallel streams",
                        "global_batch": world * B, "t_size": T, "parallelism": f"batch-sharded x{world}, no collective in the loop"},
             "iters_per_s": iters_per_s,
             "output_finite": finite,
@@ -367,7 +380,7 @@ def main():
                     r[k.replace("seconds", "us")] = r.pop(k) * 1e6
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would just wait)
-            out["cpu_baseline"] = cpu_baseline(T)
+            out["cpu_baseline"] = cpu_baseline(T, B)
         if train_leg is not None:
             out["train_step"] = train_leg
         print(json.dumps(out), flush=True)

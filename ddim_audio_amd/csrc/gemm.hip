@@ -266,133 +266,83 @@ hipError_t gemm_launch(GemmArgs g, hipStream_t s) {
 // Supported: S <= 32 (T <= 1024 for the 6-level network), S % 8 == 0, hid % 128 == 0; otherwise the caller falls back to the
 // two-GEMM path.
 // =====================================================================================================
-constexpr int MIX_BK = 128, MIX_ROWB = MIX_BK * 4 + 16;  // 528 B rows: 33 slots of 16 B (odd)
+// ---- Re(FFT2(X)) + X in one launch -------------------------------------------------------------------------------------
+// Z[b] = C_S (X[b] C_H) - S_S (X[b] S_H) + X[b]   (S <= 32 tokens, hid % 64 == 0).
+// Stage 1 (hidden DFT, exact fp32 MFMA): a workgroup owns 32 rows of the interleaved table D_H (16 output frequencies j:
+// row 2j = cos_j, 2j+1 = sin_j) and one sample; its four waves split K = hid into quarters.  v_mfma_f32_32x32x2_f32 takes one
+// k per lane half, and any pairing of k with (lane half, step) is valid as long as A and B use the same one, so every lane
+// loads its operands STRAIGHT FROM GLOBAL MEMORY in MFMA layout (16-byte loads, all issued before the first MFMA): lane
+// (r = lane % 32, h = lane / 32) holds D_H[m0 + r][k0 + 8g + 4h + i] and X[b][r][same k].  No LDS staging, no K loop, no barrier
+// before the MFMAs: the kernel is one load round plus hid/8 dependent MFMAs per wave.
+// Stage 2 (sequence DFT): the four K-quarter partials are summed in a fixed order through LDS, then
+// Z[s'][j] = sum_s C_S[s'][s] Ut_cos[j][s] - S_S[s'][s] Ut_sin[j][s] + X[s'][j] as fp32 FMA chains.
+constexpr int MIX_ROWS = 32;  // D_H rows per workgroup
 struct MixSmem {
-    static constexpr int A_BYTES = 64 * MIX_ROWB, B_BYTES = 32 * MIX_ROWB;  // B: up to 32 token rows
-    static constexpr int STAGE = A_BYTES + B_BYTES;
-    static size_t bytes(int S) { return (size_t)2 * STAGE + (size_t)S * 2 * S * 4; }
+    static size_t bytes(int S) { return (size_t)(4 * MIX_ROWS * 33 + S * 2 * S) * 4; }
 };
 __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__ dft_hidden /*[2hid][hid]*/,
                                                        const float* __restrict__ dft_seq /*[S][2S]*/,
                                                        const float* __restrict__ X /*[B][S][hid]*/, float* __restrict__ Z, int S,
                                                        int hid) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    char* const sAB = sm;                                      // 2 stages x (A 64 rows | B 32 rows)
-    float* const dsl = (float*)(sm + 2 * MixSmem::STAGE);      // dft_seq copy [S][2S]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const part = (float*)sm;                            // [4 K-quarters][32 rows][33]
+    float* const dsl = part + 4 * MIX_ROWS * 33;               // dft_seq copy [S][2S]
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, kh = wave >> 1;                   // row half of the 64 Ut rows, k half of every chunk
-    const int m0 = blockIdx.x * 64, b = blockIdx.y;
-    const float* A = dft_hidden + (size_t)m0 * hid;
-    const float* Xb = X + (size_t)b * S * hid;
-    for (int i = tid; i < S * 2 * S; i += 256) dsl[i] = dft_seq[i];
-
-    constexpr int F4 = MIX_BK / 4;                              // float4 per row per chunk
-    constexpr int NA = 64 * F4 / 256, NB = 32 * F4 / 256;
-    // two chunks of loads are kept in flight in registers (the K loop is latency-bound): set 1 = chunk kc+1, set 2 = kc+2
-    f32x4_t ra1[NA], rb1[NB], ra2[NA], rb2[NB];  // native vectors: HIP's float4 struct arrays were left in scratch memory
-#define DDIMX_MIX_LOAD(RA, RB, K0)                                                                                     \
-    do {                                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                               \
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
-            RA[i] = *(const f32x4_t*)(A + (size_t)row * hid + (K0) + kq);                                               \
-        }                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
-            RB[i] = row < S ? *(const f32x4_t*)(Xb + (size_t)row * hid + (K0) + kq) : (f32x4_t)(0.f);                  \
-        }                                                                                                              \
-    } while (0)
-#define DDIMX_MIX_STORE(BUF, RA, RB)                                                                                   \
-    do {                                                                                                               \
-        char* pa_ = sAB + (BUF) * MixSmem::STAGE;                                                                      \
-        char* pb_ = pa_ + MixSmem::A_BYTES;                                                                            \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                               \
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
-            *(f32x4_t*)(pa_ + row * MIX_ROWB + kq * 4) = RA[i];                                                         \
-        }                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;                                           \
-            *(f32x4_t*)(pb_ + row * MIX_ROWB + kq * 4) = RB[i];                                                         \
-        }                                                                                                              \
-    } while (0)
-    f32x16_t acc0;  // this wave's 32 Ut rows x 32 token columns, over its half of every k chunk
+    const int m0 = blockIdx.x * MIX_ROWS, b = blockIdx.y;
+    const int kq_len = hid / 4, k0 = kq * kq_len;
+    const float* arow = dft_hidden + (size_t)(m0 + l31) * hid + k0 + 4 * h;
+    const float* brow = X + ((size_t)b * S + (l31 < S ? l31 : 0)) * hid + k0 + 4 * h;
+    const bool bvalid = l31 < S;
+    f32x16_t acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-    const int nk = hid / MIX_BK;
-    DDIMX_MIX_LOAD(ra1, rb1, 0);
-    if (nk > 1) DDIMX_MIX_LOAD(ra2, rb2, MIX_BK);
-    DDIMX_MIX_STORE(0, ra1, rb1);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int G = 16;  // 8-float groups per pass: 16 x (A + B) x 4 registers in flight
+    for (int g0 = 0; g0 < kq_len / 8; g0 += G) {
+        f32x4_t ra[G], rb[G];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra1[i] = ra2[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb1[i] = rb2[i];
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk) DDIMX_MIX_LOAD(ra2, rb2, (kc + 2) * MIX_BK);
-        const char* pa = sAB + (kc & 1) * MixSmem::STAGE + (wm * 32 + l31) * MIX_ROWB + h * 16;
-        const char* pb = sAB + (kc & 1) * MixSmem::STAGE + MixSmem::A_BYTES + l31 * MIX_ROWB + h * 16;
-#pragma unroll
-        for (int kg = 0; kg < MIX_BK / 16; ++kg) {             // this wave's half of the chunk: 8 groups of 8 floats
-            const int off = (kh * (MIX_BK / 16) + kg) * 32;
-            const uint4 a = *(const uint4*)(pa + off);
-            const uint4 b0 = *(const uint4*)(pb + off);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b0.x), acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b0.y), acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b0.z), acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b0.w), acc0, 0, 0, 0);
+        for (int g = 0; g < G; ++g) {
+            ra[g] = *(const f32x4_t*)(arow + (g0 + g) * 8);
+            rb[g] = bvalid ? *(const f32x4_t*)(brow + (g0 + g) * 8) : (f32x4_t)(0.f);
         }
-        if (kc + 1 < nk) {
-            DDIMX_MIX_STORE((kc + 1) & 1, ra1, rb1);  // chunk kc+1 was requested an iteration ago
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra1[i] = ra2[i];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) rb1[i] = rb2[i];
+        for (int g = 0; g < G; ++g) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][0], rb[g][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][1], rb[g][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][2], rb[g][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][3], rb[g][3], acc, 0, 0, 0);
         }
-        __syncthreads();
     }
-    // Ut -> LDS, de-interleaved: utc[j][s] = Ut[2j][s] (cos rows), uts[j][s] = Ut[2j+1][s]; row stride 65 floats.
-    // The k halves are summed in a fixed order (kh = 0 writes, barrier, kh = 1 adds).
-    float* const utc = (float*)sAB;
-    float* const uts = utc + 32 * 65;
-    auto put = [&](bool add) __attribute__((always_inline)) {
+    for (int i = tid; i < S * 2 * S; i += 256) dsl[i] = dft_seq[i];
+    // this wave's partial Ut[32 rows][tokens] -> its LDS slab (D layout of the MFMA: row = (r & 3) + 8 (r >> 2) + 4 h, col = l31)
+    float* const mine = part + kq * MIX_ROWS * 33;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // Ut row inside the block (D layout of the MFMA)
-            float* dst = ((m & 1) ? uts : utc) + (m >> 1) * 65;
-            if (l31 < S) dst[l31] = add ? dst[l31] + acc0[r] : acc0[r];
-        }
-    };
-    if (kh == 0) put(false);
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
     __syncthreads();
-    if (kh == 1) put(true);
+    // fixed-order sum of the four K quarters, in place in slab 0
+    for (int i = tid; i < MIX_ROWS * 32; i += 256) {
+        const int o = (i >> 5) * 33 + (i & 31);
+        part[o] = ((part[o] + part[MIX_ROWS * 33 + o]) + part[2 * MIX_ROWS * 33 + o]) + part[3 * MIX_ROWS * 33 + o];
+    }
     __syncthreads();
-    // stage 2: thread = (output frequency j = tid % 32, rows s' = tid / 32 + 8 i); dft_seq row = [cos | -sin]
-    const int j = tid & 31, s0 = tid >> 5;
-    const float* uc = utc + j * 65;
-    const float* us = uts + j * 65;
-    for (int sp = s0; sp < S; sp += 8) {
+    // stage 2: thread = (output frequency j = tid % 16, rows s' = tid / 16 + 16 i); dft_seq row = [cos | -sin]
+    const int j = tid & 15, s0 = tid >> 4;
+    const float* uc = part + (2 * j) * 33;
+    const float* us = part + (2 * j + 1) * 33;
+    for (int sp = s0; sp < S; sp += 16) {
         const float* dr = dsl + (size_t)sp * 2 * S;
         float a = 0.f;
         for (int s2 = 0; s2 < S; ++s2) a = fmaf(dr[s2], uc[s2], a);
         for (int s2 = 0; s2 < S; ++s2) a = fmaf(dr[S + s2], us[s2], a);
-        const size_t o = ((size_t)b * S + sp) * hid + blockIdx.x * 32 + j;
+        const size_t o = ((size_t)b * S + sp) * hid + blockIdx.x * (MIX_ROWS / 2) + j;
         Z[o] = a + X[o];
     }
 }
-#undef DDIMX_MIX_LOAD
-#undef DDIMX_MIX_STORE
-bool fnet_mix_supported(int S, int hid) { return S >= 8 && S <= 32 && S % 8 == 0 && hid % MIX_BK == 0 && hid % 32 == 0; }
+bool fnet_mix_supported(int S, int hid) { return S >= 8 && S <= 32 && S % 8 == 0 && hid % 512 == 0; }
 hipError_t fnet_mix_launch(const float* dft_hidden, const float* dft_seq, const float* X, float* Z, int B, int S, int hid,
                            hipStream_t s) {
     if (!fnet_mix_supported(S, hid)) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    const size_t lds = MixSmem::bytes(32);
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)fnet_mix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(fnet_mix_kernel, dim3(2 * hid / 64, B), dim3(256), MixSmem::bytes(S), s, dft_hidden, dft_seq, X, Z, S, hid);
+    hipLaunchKernelGGL(fnet_mix_kernel, dim3(2 * hid / MIX_ROWS, B), dim3(256), MixSmem::bytes(S), s, dft_hidden, dft_seq, X, Z, S, hid);
     return hipGetLastError();
 }
 

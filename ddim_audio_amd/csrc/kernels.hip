@@ -320,45 +320,52 @@ hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float*
 // GroupNorm finalisation: partial (sum, sumsq) slabs -> per-(sample, channel) scale / shift
 //   scale = rstd_g * gamma_c ; shift = beta_c - mean_g * scale     (torch.nn.GroupNorm, biased variance)
 // =====================================================================================================
+// One 256-thread block per (group, sample): every thread sums a strided share of the (sum, sumsq) pairs in fp64 (8-byte loads,
+// up to four issued before the first use), then wave butterflies + one LDS exchange (fixed order) give the group's totals.
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ stats, int nparts, int Cs, int C,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           float* __restrict__ scale, float* __restrict__ shift,
                                                           float* __restrict__ mr_out) {
     __shared__ double rs[4], rq[4];
-    __shared__ float mr[2];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int GS = C / kGroups, reps = Cs / C;
-    const int per_part = reps * GS;
+    const int per_part = reps * GS, total = nparts * per_part;
+    const float2* base = (const float2*)stats + (size_t)b * nparts * Cs;
     double s = 0.0, q = 0.0;
-    for (int i = tid; i < nparts * per_part; i += 256) {
-        const int part = i / per_part, r = i % per_part;
-        const int vc = (r / GS) * C + g * GS + r % GS;
-        const float* p = stats + (((size_t)b * nparts + part) * Cs + vc) * 2;
-        s += (double)p[0];
-        q += (double)p[1];
+    for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            v[u] = make_float2(0.f, 0.f);
+            if (i < total) {
+                const int part = i / per_part, r = i - part * per_part;
+                const int rep = r / GS;
+                v[u] = base[(size_t)part * Cs + rep * C + g * GS + (r - rep * GS)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
     }
+#pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
     if ((tid & 63) == 0) { rs[tid >> 6] = s; rq[tid >> 6] = q; }
     __syncthreads();
-    if (tid == 0) {
-        const double S = rs[0] + rs[1] + rs[2] + rs[3], Q = rq[0] + rq[1] + rq[2] + rq[3];
-        const double mean = S / count;
-        double var = Q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mr[0] = (float)mean;
-        mr[1] = (float)(1.0 / sqrt(var + (double)eps));
-        if (mr_out) {  // saved for the backward pass: [B][groups][2] = (mean, rstd)
-            mr_out[((size_t)b * kGroups + g) * 2 + 0] = mr[0];
-            mr_out[((size_t)b * kGroups + g) * 2 + 1] = mr[1];
-        }
+    const double S = (rs[0] + rs[1]) + (rs[2] + rs[3]), Q = (rq[0] + rq[1]) + (rq[2] + rq[3]);
+    const double mean = S / count;
+    double var = Q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+    if (mr_out && tid == 0) {  // saved for the backward pass: [B][groups][2] = (mean, rstd)
+        mr_out[((size_t)b * kGroups + g) * 2 + 0] = mf;
+        mr_out[((size_t)b * kGroups + g) * 2 + 1] = rf;
     }
-    __syncthreads();
     for (int i = tid; i < GS; i += 256) {
         const int c = g * GS + i;
-        const float sc = mr[1] * gamma[c];
+        const float sc = rf * gamma[c];
         scale[(size_t)b * C + c] = sc;
-        shift[(size_t)b * C + c] = (beta ? beta[c] : 0.f) - mr[0] * sc;
+        shift[(size_t)b * C + c] = (beta ? beta[c] : 0.f) - mf * sc;
     }
 }
 
