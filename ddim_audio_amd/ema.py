@@ -64,9 +64,11 @@ class EMAHelper(object):
 
     def ema_copy(self, module):
         inner = self._unwrap(module)
+        """A second model instance holding the EMA weights (reference models/ema.py:32-45; unused by its runner)."""
         copy = type(inner)(inner._full_config) if hasattr(inner, "_full_config") else None
         if copy is None:
             raise NotImplementedError("ema_copy needs the full config; it is unused by the reference runner")
+        copy.to(next(inner.parameters()).device)
         copy.load_state_dict(inner.state_dict())
         self.ema(copy)
         return copy

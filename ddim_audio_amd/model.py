@@ -283,6 +283,7 @@ class Model(_Node):
     def __init__(self, config):
         super().__init__()
         self.config = config.model  # same attribute as the reference (:174)
+        self._full_config = config  # what EMAHelper.ema_copy needs to build a second instance (models/ema.py:32-45)
         self._inventory = build_parameters(self, config)
         self.embedding_size = embedding_sizes(config.model)
         self._n_timesteps = config.diffusion.num_diffusion_timesteps
