@@ -19,28 +19,44 @@ hipError_t wgrad_launch(int dtype, int mode, int ci, int co, const WgradArgs& a,
     return dtype == DT_BF16 ? wgrad_launch_bf16(mode, ci, co, a, nsplit, s) : wgrad_launch_f32(mode, ci, co, a, nsplit, s);
 }
 
-// dst[co][ci][tap] = sum_s partial[s][tap][co][ci]; 4 threads share an output (splits s = q, q+4, ...), folded in a
-// fixed order through LDS
+// dst[co][ci][tap] = sum_s partial[s][tap][co][ci]; KS threads share an output (splits s = q, q+KS, ...: loads unrolled so
+// that eight are in flight per thread), folded in a fixed order through LDS
+template <int KS>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int ntaps, int co,
                                                            int ci, float* __restrict__ dst) {
-    __shared__ double red[4][64];
+    constexpr int OUT = 256 / KS;
+    __shared__ double red[KS][OUT];
     const int n = ntaps * co * ci;
-    const int o64 = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + o64;
+    const int ol = threadIdx.x % OUT, q = threadIdx.x / OUT;
+    const int i = blockIdx.x * OUT + ol;
     double s = 0.0;
-    if (i < n)
-        for (int k = q; k < nsplit; k += 4) s += (double)partial[(size_t)k * n + i];
-    red[q][o64] = s;
+    if (i < n) {
+        int k = q;
+        for (; k + 7 * KS < nsplit; k += 8 * KS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(k + u * KS) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; k < nsplit; k += KS) s += (double)partial[(size_t)k * n + i];
+    }
+    red[q][ol] = s;
     __syncthreads();
     if (q == 0 && i < n) {
-        s = (red[0][o64] + red[1][o64]) + (red[2][o64] + red[3][o64]);
+        s = 0.0;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) s += red[k][ol];
         const int c = i % ci, o = (i / ci) % co, tap = i / (ci * co);
         dst[((size_t)o * ci + c) * ntaps + tap] = (float)s;
     }
 }
 hipError_t wgrad_reduce_launch(const float* partial, int nsplit, int ntaps, int co, int ci, float* dst, hipStream_t s) {
     const int n = ntaps * co * ci;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partial, nsplit, ntaps, co, ci, dst);
+    if (nsplit >= 64)  // many thin slabs (levels 0-2): 16 threads per output
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((n + 15) / 16), dim3(256), 0, s, partial, nsplit, ntaps, co, ci, dst);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((n + 63) / 64), dim3(256), 0, s, partial, nsplit, ntaps, co, ci, dst);
     return hipGetLastError();
 }
 
@@ -172,24 +188,36 @@ hipError_t gn_bwd_finalize_launch(const float* stats, int nparts, int C, double 
 }
 
 // dst[c] = sum_b src[b * stride + c]: 32 columns x 8 row-lanes per block, lanes folded in a fixed order
+// 16 columns x 16 row slices per block; eight loads in flight per thread
+__device__ __forceinline__ double colsum_slice(const float* __restrict__ src, int B, long long stride, int c, int rl) {
+    double s = 0.0;
+    int b = rl;
+    for (; b + 7 * 16 < B; b += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + u * 16) * stride + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < B; b += 16) s += (double)src[(size_t)b * stride + c];
+    return s;
+}
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ src, int B, long long stride, int C,
                                                      float* __restrict__ dst) {
-    __shared__ double red[8][32];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s = 0.0;
-    if (c < C)
-        for (int b = rl; b < B; b += 8) s += (double)src[(size_t)b * stride + c];
-    red[rl][cl] = s;
+    __shared__ double red[16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    red[rl][cl] = c < C ? colsum_slice(src, B, stride, c, rl) : 0.0;
     __syncthreads();
     if (rl == 0 && c < C) {
-        s = 0.0;
-        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
         dst[c] = (float)s;
     }
 }
 hipError_t colsum_launch(const float* src, int B, long long stride, int C, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 31) / 32), dim3(256), 0, s, src, B, stride, C, dst);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(256), 0, s, src, B, stride, C, dst);
     return hipGetLastError();
 }
 // the same for up to kMax (src, dst) pairs in one launch (the entries travel as kernel arguments): the backward defers
@@ -530,8 +558,8 @@ hipError_t ln_bwd_launch(int x_dtype, const float* dy, const void* x, const floa
         hipLaunchKernelGGL(ln_bwd_kernel<__bf16>, dim3(nb), dim3(256), 0, s, dy, (const __bf16*)x, add, add_rows, stat, gamma, dx, partial, M, N);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, dy, (const float*)x, add, add_rows, stat, gamma, dx, partial, M, N);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, s, partial, nb, 2ll * N, N, dgamma);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, s, partial + N, nb, 2ll * N, N, dbeta);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 15) / 16), dim3(256), 0, s, partial, nb, 2ll * N, N, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 15) / 16), dim3(256), 0, s, partial + N, nb, 2ll * N, N, dbeta);
     return hipGetLastError();
 }
 

@@ -92,6 +92,8 @@ def test_model_backward_golden(golden, mode, name, shape, seed):
         assert err <= tol, f"{pname}: max err {err:.3e} x rms (tol {tol})"
         nerr = abs(float(flat.double().square().sum()) ** 0.5 - ref_norm) / max(ref_norm, 1e-4 * total)
         assert nerr <= (5e-4 if dt == G.F32 else 6e-2), f"{pname}: norm err {nerr:.3e}"
+    print(f"[backward golden {name} {'f32' if dt == G.F32 else 'bf16'}] worst element {worst:.3e} x rms, global norm rel err "
+          f"{abs(got_total ** 0.5 - total) / total:.2e}")
     assert abs(got_total ** 0.5 - total) <= (1e-4 if dt == G.F32 else 2e-2) * total
 
 
@@ -263,12 +265,15 @@ def _ragged_case(mode, shape, tt):
     want.backward()
     assert abs(float(loss) - float(want)) <= (1e-5 if dt == G.F32 else 2e-3) * float(want)
     total = sum(float(p.grad.double().square().sum()) for p in params.values()) ** 0.5
+    worst = 0.0
     for name, p in m.named_parameters():
         ref = params[name].grad
         got = p.grad.detach().cpu()
         scale = max(float(ref.double().square().mean().sqrt()), 1e-4 * total / ref.numel() ** 0.5)
         err = float((got - ref).abs().max()) / scale
+        worst = max(worst, err)
         assert err <= (2e-3 if dt == G.F32 else 0.6), f"{name}: {err:.3e} x rms"
+    print(f"[backward ragged {shape} {'f32' if dt == G.F32 else 'bf16'}] worst element {worst:.3e} x rms")
 
 
 def test_training_reduces_the_loss_and_state_dicts_roundtrip():
