@@ -39,6 +39,8 @@ _SIGS = {
     "ddimx_pack_weights": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "ddimx_unet_fwd": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_void_p]),
+    "ddimx_unet_fwd_forked": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p,
+                                      c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p), c_int, ctypes.c_uint]),
     "ddimx_packed_bwd_bytes": (c_longlong, [c_void_p]),
     "ddimx_pack_weights_bwd": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p]),
     "ddimx_train_tape_bytes": (c_longlong, [c_void_p, c_int, c_int]),

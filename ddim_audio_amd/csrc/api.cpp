@@ -281,6 +281,9 @@ struct Ws {
     float *stats, *scale, *shift;
     float *ln0, *X, *Ut, *Z, *Y, *Hb, *O, *gpart;
     size_t total;
+    size_t stats_per_sample, gpart_per_sample;  // floats: the statistics / split-K scratch one sample can need (max over ops)
+    size_t h_per_sample;                        // bytes of h1 / h2 one sample can need (its largest level)
+    int cmax;
 };
 
 static size_t conv_stats_floats(int dtype, int mode, int cin, int cout, int B, int Hv, int Wv) {
@@ -328,6 +331,9 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
     }
     w->h1 = cv.take(hmax);
     w->h2 = cv.take(hmax);
+    w->stats_per_sample = stats_f / B;  // every term above is B x (per-sample slab)
+    w->h_per_sample = hmax / B;
+    w->cmax = cmax;
     w->stats = (float*)cv.take(stats_f * 4);
     w->scale = (float*)cv.take((size_t)B * cmax * 4);
     w->shift = (float*)cv.take((size_t)B * cmax * 4);
@@ -350,6 +356,7 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
             const size_t n = (size_t)kMaxSplitK * q[3] * q[0] * q[1];  // the split depends on the per-sample shape only; size for the cap
             if (n > mx) mx = n;
         }
+        w->gpart_per_sample = mx / B;  // every shape above has B in its row or batch count
         w->gpart = (float*)cv.take(mx * 4);
     }
     w->total = cv.off;
@@ -716,6 +723,19 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
 
 int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace,
                    long long workspace_bytes, const float* x, const int64_t* t, float* eps, int B, int T, void* stream) {
+    return ddimx_unet_fwd_forked(h, packed, tables, workspace, workspace_bytes, x, t, eps, B, T, stream, nullptr, nullptr, 0, 0);
+}
+
+// Model.forward with part of the network run as TWO batch shards on two streams.  Every op is per sample and its launch plan
+// depends on the sample's size only, so an op over samples [0, B) equals the same op over [0, B/2) and [B/2, B): results are
+// bit-identical whatever the mask.  fork_mask bit l: the ops whose OUTPUT lives on level l (its Residual_Blocks, the Downsample
+// into it, the Upsample into it, the edge convs for level 0) run as two shards, shard 0 on `stream`, shard 1 on `aux_stream`;
+// bit 16: the FNet bottleneck.  Consecutive sharded ops stay forked (the shards drift apart freely); the streams are joined
+// in front of the next unsharded op.  Where it pays is measured, not assumed: the full-chip, HBM-bound levels
+// and the FNet gain from a second stream covering launch gaps and GroupNorm finalisation; the latency-bound deep levels lose.
+int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
+                          const float* x, const int64_t* t, float* eps, int B, int T, void* stream, void* aux_stream,
+                          void* const* events, int n_events, unsigned fork_mask) {
     if (!h || !packed || !tables || !workspace || !x || !t || !eps) return fail("ddimx_unet_fwd: null argument");
     const ddimx_ctx* c = h;
     const ddimx_config& f = c->cfg;
@@ -725,8 +745,44 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
     Ws w;
     carve(c, (char*)workspace, B, T, &w);
     if ((long long)w.total > workspace_bytes) return fail("workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = (hipStream_t)stream, sa = (hipStream_t)aux_stream;
+    if (!sa || !events || n_events < 2 || B < 2) fork_mask = 0;
+    int ev_used = 0;  // every fork and every join records an event of its own: nothing is re-recorded inside one capture
     const int dt = c->dtype;
+    const size_t es = esz(dt);
+    const int bh = B / 2;  // shard 0 = samples [0, bh), shard 1 = [bh, B)
+    bool forked = false;
+    // fork / join in front of an op, as its shardedness requires
+    auto sync_for = [&](bool sharded) -> int {
+        if (sharded == forked) return 0;
+        if (ev_used >= n_events) return fail("ddimx_unet_fwd_forked: %d events are not enough for this fork mask", n_events);
+        hipEvent_t ev = (hipEvent_t)events[ev_used++];
+        if (sharded) {
+            HIPCHK(hipEventRecord(ev, s));
+            HIPCHK(hipStreamWaitEvent(sa, ev, 0));
+        } else {
+            HIPCHK(hipEventRecord(ev, sa));
+            HIPCHK(hipStreamWaitEvent(s, ev, 0));
+        }
+        forked = sharded;
+        return 0;
+    };
+    auto lvl_on = [&](int l) { return (fork_mask >> l) & 1u; };
+    auto act_bytes = [&](int l) { return (size_t)(T >> l) * (f.f_size >> l) * f.ch[l] * es; };  // one sample's activation on level l
+    struct Lane { int b0, n; hipStream_t st; };
+    // runs `op(lane)` once over the whole batch or once per shard
+    auto for_lanes = [&](bool sharded, auto&& op) -> int {
+        CHK(sync_for(sharded));
+        if (!sharded) return op(Lane{0, B, s});
+        CHK(op(Lane{bh, B - bh, sa}));
+        return op(Lane{0, bh, s});
+    };
+    auto at = [&](const void* p, size_t per_sample, int b0) { return (void*)((char*)const_cast<void*>(p) + per_sample * b0); };
+    // scratch shared by all levels (h1 / h2, statistics, scale / shift): a shard's share starts at b0 x (the most one sample
+    // can need on ANY level) -- the two shards drift apart and may be on different levels at the same time
+    auto stats_of = [&](const Lane& ln) { return w.stats + w.stats_per_sample * ln.b0; };
+    auto scale_of = [&](const Lane& ln) { return w.scale + (size_t)w.cmax * ln.b0; };
+    auto shift_of = [&](const Lane& ln) { return w.shift + (size_t)w.cmax * ln.b0; };
 
     if (tables->temb_table) {
         HIPCHK(temb_gather_launch(tables->temb_table, t, w.temb, B, c->E, s));
@@ -735,26 +791,41 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
                      pf(c, packed, c->tb[1]), pf(c, packed, c->tw[2]), pf(c, packed, c->tb[2]), w.temb_h1, w.temb_h2, w.temb,
                      B, 128, 512, c->E, s));
     }
+    auto resblock = [&](int l, const void* in, void* out, const float* temb_chunk, const RBW& rbw, int np, int cs, bool want_stats,
+                        int* ynp) -> int {
+        const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        return for_lanes(lvl_on(l), [&](const Lane& ln) -> int {
+            return run_resblock(dt, C, at(in, act_bytes(l), ln.b0), at(out, act_bytes(l), ln.b0), temb_chunk + (size_t)c->E * ln.b0, c->E,
+                                rb_ptrs(c, packed, rbw), at(w.h1, w.h_per_sample, ln.b0), at(w.h2, w.h_per_sample, ln.b0), stats_of(ln),
+                                scale_of(ln), shift_of(ln), np, cs, want_stats, ynp, ln.n, H, W, ln.st);
+        });
+    };
 
     // ---- down path (models/diffusion.py:252-264) ----
-    HIPCHK(conv_in_launch(dt, x, pf(c, packed, c->in_w), pf(c, packed, c->in_b), w.A, w.stats, B, f.in_channels, f.ch[0], T,
-                          f.f_size, s));
+    const size_t in_per = (size_t)f.in_channels * T * f.f_size;  // fp32 NCHW elements per sample at the network boundary
+    CHK(for_lanes(lvl_on(0), [&](const Lane& ln) -> int {
+        HIPCHK(conv_in_launch(dt, x + in_per * ln.b0, pf(c, packed, c->in_w), pf(c, packed, c->in_b), at(w.A, act_bytes(0), ln.b0),
+                              stats_of(ln), ln.n, f.in_channels, f.ch[0], T, f.f_size, ln.st));
+        return 0;
+    }));
     int np = conv_in_nparts(T, f.f_size), cs = f.ch[0];
     const void* cur = w.A;
     int bi = 0;
     for (int l = 0; l < L; ++l) {
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
         if (l > 0) {
-            ConvCall d = {dt, DOWN4, f.ch[l - 1], C, cur, pv(c, packed, c->down_w[l]), pf(c, packed, c->down_b[l]), nullptr, 0,
-                          nullptr, nullptr, XF_NONE, 0, nullptr, w.xd[l], w.stats, B, H * 2, W * 2};
-            CHK(run_conv(d, s, &np, &cs));
+            CHK(for_lanes(lvl_on(l), [&](const Lane& ln) -> int {
+                ConvCall d = {dt, DOWN4, f.ch[l - 1], C, at(cur, act_bytes(l - 1), ln.b0), pv(c, packed, c->down_w[l]),
+                              pf(c, packed, c->down_b[l]), nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr,
+                              at(w.xd[l], act_bytes(l), ln.b0), stats_of(ln), ln.n, H * 2, W * 2};
+                return run_conv(d, ln.st, &np, &cs);
+            }));
             cur = w.xd[l];
         }
         for (int r = 0; r < f.res[l]; ++r, ++bi) {
             const bool last = (r == f.res[l] - 1);
             int ynp = 0;
-            CHK(run_resblock(dt, C, cur, w.xd[l], w.temb + c->emb_off_down[bi], c->E, rb_ptrs(c, packed, c->down_rb[l][r]),
-                             w.h1, w.h2, w.stats, w.scale, w.shift, np, cs, !last, &ynp, B, H, W, s));
+            CHK(resblock(l, cur, w.xd[l], w.temb + c->emb_off_down[bi], c->down_rb[l][r], np, cs, !last, &ynp));
             cur = w.xd[l];
             np = ynp; cs = C;
         }
@@ -762,8 +833,20 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
     }
     // ---- bottleneck (models/diffusion.py:267-279) + first skip add (:284) ----
     const int S = T >> (L - 1), CL = f.ch[L - 1];
-    CHK(run_fnet(c, packed, tables, w, w.xd[L - 1], B, S, s));
-    HIPCHK(resid_launch(dt, w.xd[L - 1], w.O, 1, nullptr, nullptr, w.xu[L - 1], w.stats, B, S * c->Fr, CL, s));
+    CHK(for_lanes((fork_mask >> 16) & 1u, [&](const Lane& ln) -> int {
+        Ws v = w;  // this shard's rows of every token matrix, its share of the split-K scratch
+        const size_t rows = (size_t)ln.b0 * S;
+        v.ln0 = w.ln0 + rows * c->width; v.X = w.X + rows * f.fnet_hidden; v.Z = w.Z + rows * f.fnet_hidden;
+        v.Y = w.Y + rows * f.fnet_hidden; v.Hb = w.Hb + rows * f.fnet_inter; v.O = w.O + rows * c->width;
+        v.Ut = w.Ut + (size_t)ln.b0 * 2 * f.fnet_hidden * S;
+        v.gpart = w.gpart + w.gpart_per_sample * ln.b0;
+        return run_fnet(c, packed, tables, v, at(w.xd[L - 1], act_bytes(L - 1), ln.b0), ln.n, S, ln.st);
+    }));
+    CHK(for_lanes(lvl_on(L - 1), [&](const Lane& ln) -> int {
+        HIPCHK(resid_launch(dt, at(w.xd[L - 1], act_bytes(L - 1), ln.b0), w.O + (size_t)ln.b0 * S * c->width, 1, nullptr, nullptr,
+                            at(w.xu[L - 1], act_bytes(L - 1), ln.b0), stats_of(ln), ln.n, S * c->Fr, CL, ln.st));
+        return 0;
+    }));
     np = resid_nparts(dt, S * c->Fr, CL); cs = CL;
     // ---- up path (models/diffusion.py:281-292) ----
     bi = 0;
@@ -772,18 +855,24 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
         for (int r = 0; r < f.res[l]; ++r, ++bi) {
             const bool last = (r == f.res[l] - 1);
             int ynp = 0;
-            CHK(run_resblock(dt, C, w.xu[l], w.xu[l], w.temb + c->emb_off_up[bi], c->E, rb_ptrs(c, packed, c->up_rb[l][r]),
-                             w.h1, w.h2, w.stats, w.scale, w.shift, np, cs, !last, &ynp, B, H, W, s));
+            CHK(resblock(l, w.xu[l], w.xu[l], w.temb + c->emb_off_up[bi], c->up_rb[l][r], np, cs, !last, &ynp));
             np = ynp; cs = C;
         }
         if (l > 0) {
-            ConvCall u = {dt, UP4, C, f.ch[l - 1], w.xu[l], pv(c, packed, c->up_w[l]), pf(c, packed, c->up_b[l]), nullptr, 0,
-                          nullptr, nullptr, XF_NONE, 0, w.xd[l - 1], w.xu[l - 1], w.stats, B, H, W};
-            CHK(run_conv(u, s, &np, &cs));
+            CHK(for_lanes(lvl_on(l - 1), [&](const Lane& ln) -> int {
+                ConvCall u = {dt, UP4, C, f.ch[l - 1], at(w.xu[l], act_bytes(l), ln.b0), pv(c, packed, c->up_w[l]), pf(c, packed, c->up_b[l]),
+                              nullptr, 0, nullptr, nullptr, XF_NONE, 0, at(w.xd[l - 1], act_bytes(l - 1), ln.b0),
+                              at(w.xu[l - 1], act_bytes(l - 1), ln.b0), stats_of(ln), ln.n, H, W};
+                return run_conv(u, ln.st, &np, &cs);
+            }));
         }
     }
-    HIPCHK(conv_out_launch(dt, w.xu[0], w.A, pf(c, packed, c->out_w), pf(c, packed, c->out_b), eps, B, f.ch[0],
-                           f.in_channels, T, f.f_size, s));
+    CHK(for_lanes(lvl_on(0), [&](const Lane& ln) -> int {
+        HIPCHK(conv_out_launch(dt, at(w.xu[0], act_bytes(0), ln.b0), at(w.A, act_bytes(0), ln.b0), pf(c, packed, c->out_w),
+                               pf(c, packed, c->out_b), eps + in_per * ln.b0, ln.n, f.ch[0], f.in_channels, T, f.f_size, ln.st));
+        return 0;
+    }));
+    CHK(sync_for(false));  // leave with everything joined into `stream`
     return 0;
 }
 

@@ -302,6 +302,12 @@ class Model(_Node):
         self._dirty = True
         self._tables = {}
         self._workspace = None
+        # which parts of the eval forward run as two batch shards on two streams (ddimx_unet_fwd_forked): bit l = level l,
+        # bit 16 = the FNet; 0 turns it off.  Default: everything -- measured: the gain needs the two shards to
+        # run independently from the input conv to the output conv; forking only some levels (every join is a rendezvous)
+        # gives nothing, although per-op microbenchmarks say the deep levels alone prefer whole-batch launches.
+        import os
+        self.fork_mask = int(os.environ.get("DDIMX_FORK_MASK", hex(((1 << len(config.model.ch)) - 1) | 0x10000)), 0)
         if dev == "cuda":
             self.to("cuda")  # like nn.Module.type("torch.cuda.FloatTensor") in the reference (:234-235)
 
@@ -316,6 +322,7 @@ class Model(_Node):
 
     def _apply(self, fn, *a, **k):
         self._dirty = True
+        self._fork_res = None
         self._tables = {}
         self._workspace = None
         self._packed = None
@@ -472,10 +479,21 @@ class Model(_Node):
     # -- forward -------------------------------------------------------------------------------------
     def forward_slot(self, input, t, slot):
         """``forward`` over workspace ``slot``: concurrent calls on different HIP streams (the sampler's batch shards) must
-        not share scratch memory.  Inference only."""
-        return self.forward(input, t, _slot=slot)
+        not share scratch memory.  Inference only; the in-library fork is off (the caller already runs shards in parallel)."""
+        return self.forward(input, t, _slot=slot, _fork=False)
 
-    def forward(self, input, t, _slot=0):
+    def _fork_resources(self, device):
+        """Second stream + fork / join events for ``ddimx_unet_fwd_forked`` (created once per device)."""
+        res = getattr(self, "_fork_res", None)
+        if res is None or res[0] != device:
+            aux = torch.cuda.Stream(device=device)
+            evs = [torch.cuda.Event() for _ in range(2 * len(self.config.ch) + 4)]  # one per fork / join of a call
+            for e in evs:
+                e.record()  # torch creates the hipEvent lazily: force it, the library re-records it
+            res = self._fork_res = (device, aux, evs)
+        return res[1], res[2]
+
+    def forward(self, input, t, _slot=0, _fork=True):
         """input [B, C, T, F] fp32 on the GPU, t [B] int64 -> eps [B, C, T, F] fp32 (reference :237-294).
         eval mode or no_grad: ``ddimx_unet_fwd``.  train mode with grad enabled: ``ddimx_unet_fwd_train`` (dropout active,
         tape kept) as an autograd node whose backward fills every parameter's gradient (``ddimx_unet_bwd``)."""
@@ -514,7 +532,17 @@ class Model(_Node):
             tt_ptr = self._temb_table.data_ptr() if (not self.training and getattr(self, "_temb_table", None) is not None) else None
             tables = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr(), tt_ptr)
             import ctypes
-            _lib.check(lib.ddimx_unet_fwd(self._handle, _lib.ptr(self._packed), ctypes.byref(tables),
-                                          _lib.ptr(wsp), wsp.numel(), _lib.ptr(x), _lib.ptr(tt),
-                                          _lib.ptr(out), b, t_len, _lib.stream()))
+            mask = self.fork_mask if (_fork and b >= 4) else 0
+            if mask:
+                # the full-chip levels and the FNet run as two batch shards on two streams (bit-identical results; DESIGN
+                # section 5); everything is joined back into the current stream before the call returns
+                aux, evs = self._fork_resources(dev)
+                _lib.check(lib.ddimx_unet_fwd_forked(self._handle, _lib.ptr(self._packed), ctypes.byref(tables), _lib.ptr(wsp),
+                                                     wsp.numel(), _lib.ptr(x), _lib.ptr(tt), _lib.ptr(out), b, t_len, _lib.stream(),
+                                                     ctypes.c_void_p(aux.cuda_stream),
+                                                     (ctypes.c_void_p * len(evs))(*[e.cuda_event for e in evs]), len(evs), mask))
+            else:
+                _lib.check(lib.ddimx_unet_fwd(self._handle, _lib.ptr(self._packed), ctypes.byref(tables),
+                                              _lib.ptr(wsp), wsp.numel(), _lib.ptr(x), _lib.ptr(tt),
+                                              _lib.ptr(out), b, t_len, _lib.stream()))
         return out

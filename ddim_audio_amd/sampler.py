@@ -29,7 +29,9 @@ def _default_branches(batch):
     env = os.environ.get("DDIMX_BRANCHES")
     if env:
         return max(1, min(int(env), batch))
-    return 2 if batch >= 4 else 1
+    # default since the in-library fork (ddimx_unet_fwd_forked: shards only where they pay, the latency-bound deep levels stay
+    # whole-batch launches): one branch here.  Whole-step branches remain available (DDIMX_BRANCHES=2) for comparison.
+    return 1
 
 
 class DDIMStepper:

@@ -97,6 +97,16 @@ int ddimx_unet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
                    long long workspace_bytes, const float* x, const int64_t* t, float* eps, int B, int T,
                    void* stream);
 
+/* The same forward with part of the network run as two batch shards on two streams (samples [0, B/2) on `stream`, [B/2, B) on
+ * `aux_stream`, forked and joined with caller-owned hipEvent_t -- one per fork and one per join, at most 2 * n_levels + 4 of them,
+ * none recorded twice in a call; everything is joined into `stream` on return, and the calls are capturable into one hipGraph).  fork_mask bit l (0 <= l < n_levels): the ops whose output lives on level l run
+ * sharded; bit 16: the FNet bottleneck.  Every op of the path is per sample (GroupNorm / LayerNorm / FFT are per sample:
+ * models/diffusion.py:42-56,148-167), so the result is bit-identical for every mask; aux_stream = NULL or fork_mask = 0 is
+ * ddimx_unet_fwd. */
+int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
+                          const float* x, const int64_t* t, float* eps, int B, int T, void* stream, void* aux_stream,
+                          void* const* events, int n_events, unsigned fork_mask);
+
 /* ---- training: forward that keeps a tape + whole-network backward ------------------------------------
  * The reference trains through autograd: functions/losses.py:12-18 builds the graph of Model.forward
  * (models/diffusion.py:237-294, training mode: dropout hidden_dropout_prob after the FNet projection and after each FNet

@@ -475,3 +475,36 @@ def test_staged_backward_buckets_are_final_when_their_event_fires():
         b = 0 if name.startswith("up_modules.") else (1 if name.startswith("transformer.") else 2)
         lo, hi = seen["ranges"][b]
         assert lo <= off and off + numel <= hi, name
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["f32", "bf16"])
+def test_forked_forward_is_bit_identical_for_every_mask(mode):
+    """ddimx_unet_fwd_forked: any subset of levels / the FNet run as two batch shards on two streams must give the bits of the
+    plain forward (every op is per sample, the launch plan depends on the sample's size only) -- eagerly, for an odd batch,
+    and replayed from a hipGraph with the second stream captured through the fork / join events."""
+    dtype_str, dt = mode
+    cfg, m = _eval_model(dtype_str)
+    x = synth.gaussian("fork.x", (5, 2, 64, 256)).cuda()
+    t = torch.tensor([0, 999, 123, 500, 7]).cuda()
+    with torch.no_grad():
+        m.fork_mask = 0
+        ref = m(x, t).clone()
+        for mask in (0x1, 0x3, 0x10000, 0x10003, 0x24, 0x1003F):
+            m.fork_mask = mask
+            assert torch.equal(m(x, t), ref), hex(mask)
+            assert torch.equal(m(x[:4], t[:4]), ref[:4]), hex(mask)
+        m.fork_mask = 0x10003
+        g = torch.cuda.CUDAGraph()
+        xs, ts = x.clone(), t.clone()
+        m(xs, ts)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            ys = m(xs, ts)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ys, ref)
+        xs.copy_(x.flip(0)); ts.copy_(t.flip(0))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ys, ref.flip(0))
