@@ -20,13 +20,14 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int conv_var, conv_wps, wgrad_split, fnet_mix;
+    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);
         conv_wps = geti("DDIMX_CONV_WPS", 0);
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
+        splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
     }
 };
 static const Knobs& knobs() {
@@ -260,7 +261,11 @@ static int build_plan(ddimx_ctx* c) {
 // Split-K of the FNet GEMMs is chosen from the PER-SAMPLE problem (rows of one sample, never the batch): a sample's rows are
 // then summed in the same order alone, inside any batch and on any number of GPUs (bit-identical results).
 constexpr int kMaxSplitK = 8;
-static inline int sample_splitk(int rows_per_sample, int N, int K, int bf16) { return gemm_pick_splitk(rows_per_sample, N, K, 1, bf16); }
+static inline int sample_splitk(int rows_per_sample, int N, int K, int bf16) {
+    int s = gemm_pick_splitk(rows_per_sample, N, K, 1, bf16);
+    if (const int cap = knobs().splitk_cap; cap > 0 && s > cap) s = cap;  // tuning hook (a constant cap keeps the batch invariance)
+    return s;
+}
 
 // ------------------------------------------------------------------------------------------ workspace
 struct Carver {
