@@ -482,16 +482,35 @@ class Model(_Node):
         not share scratch memory.  Inference only; the in-library fork is off (the caller already runs shards in parallel)."""
         return self.forward(input, t, _slot=slot, _fork=False)
 
-    def _fork_resources(self, device):
-        """Second stream + fork / join events for ``ddimx_unet_fwd_forked`` (created once per device)."""
+    def _fork_resources(self, device, capturing):
+        """Second stream + fork / join events for ``ddimx_unet_fwd_forked``.  An event set is never shared between eager
+        launches and a graph capture, nor between two captures (a HIP event last recorded inside a capture must not be
+        re-recorded eagerly: seen as a crash in a later synchronize): eager calls own one set, every capture takes a fresh
+        one from a small pool that eager calls keep filled (events are created by their first record, which must not happen
+        inside a capture).  Returns (aux stream, events) or None when a capture finds the pool empty (the caller then runs the
+        unforked forward: same result, bit for bit)."""
         res = getattr(self, "_fork_res", None)
-        if res is None or res[0] != device:
-            aux = torch.cuda.Stream(device=device)
-            evs = [torch.cuda.Event() for _ in range(2 * len(self.config.ch) + 4)]  # one per fork / join of a call
+        n_ev = 2 * len(self.config.ch) + 4  # one per fork / join of a call
+
+        def new_set():
+            evs = [torch.cuda.Event() for _ in range(n_ev)]
             for e in evs:
-                e.record()  # torch creates the hipEvent lazily: force it, the library re-records it
-            res = self._fork_res = (device, aux, evs)
-        return res[1], res[2]
+                e.record()  # torch creates the hipEvent lazily; the library re-records it
+            return evs
+
+        if res is None or res["device"] != device:
+            if capturing:
+                return None
+            res = self._fork_res = {"device": device, "aux": torch.cuda.Stream(device=device), "eager": new_set(), "pool": [], "used": []}
+        if not capturing:
+            while len(res["pool"]) < 2:
+                res["pool"].append(new_set())
+            return res["aux"], res["eager"]
+        if not res["pool"]:
+            return None
+        evs = res["pool"].pop()
+        res["used"].append(evs)  # stays alive with the graphs that reference it
+        return res["aux"], evs
 
     def forward(self, input, t, _slot=0, _fork=True):
         """input [B, C, T, F] fp32 on the GPU, t [B] int64 -> eps [B, C, T, F] fp32 (reference :237-294).
@@ -533,10 +552,11 @@ class Model(_Node):
             tables = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr(), tt_ptr)
             import ctypes
             mask = self.fork_mask if (_fork and b >= 4) else 0
-            if mask:
-                # the full-chip levels and the FNet run as two batch shards on two streams (bit-identical results; DESIGN
-                # section 5); everything is joined back into the current stream before the call returns
-                aux, evs = self._fork_resources(dev)
+            fr = self._fork_resources(dev, torch.cuda.is_current_stream_capturing()) if mask else None
+            if fr is not None:
+                # two batch shards on two streams (bit-identical results); everything is joined back into
+                # the current stream before the call returns
+                aux, evs = fr
                 _lib.check(lib.ddimx_unet_fwd_forked(self._handle, _lib.ptr(self._packed), ctypes.byref(tables), _lib.ptr(wsp),
                                                      wsp.numel(), _lib.ptr(x), _lib.ptr(tt), _lib.ptr(out), b, t_len, _lib.stream(),
                                                      ctypes.c_void_p(aux.cuda_stream),
