@@ -20,7 +20,7 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap;
+    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);
@@ -28,6 +28,7 @@ struct Knobs {
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
+        two_tiles = geti("DDIMX_TWO_TILES", 0);
     }
 };
 static const Knobs& knobs() {
@@ -414,6 +415,10 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         if (tiles_s / 4 > wps) wps = tiles_s / 4;  // long spectrograms (T >= 2048): at most 4 tiles per workgroup, so that a
                                                    // single sample still fills the 256 CUs
         if (q.cin >= 64 && tiles_s >= 512 && wps < 256) wps = 256;  // streamed-weight levels of long samples: 2 tiles per workgroup
+        // A/B hook (off): two tiles per workgroup at level 2 (one workgroup per CU, 64-128 tiles per sample).  Alone the launch
+        // gains 9 % at B = 8 (44.1 -> 40.3 us, profiles/r02/conv_wps_deep_levels.txt), but inside the step the two batch shards
+        // run B = 4 launches, for which it halves an already half-empty grid: 1 803 vs 1 814 sample-fwd/s.
+        if (knobs().two_tiles && g.nb == g.nout && g.lds_bytes > 80 * 1024 && tiles_s >= 64 && tiles_s <= 128 && q.mode == CONV3) wps = tiles_s / 2;
         if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
         a.tiles_per_wg = cdiv(tiles_s, wps);
         a.wgs_per_sample = cdiv(tiles_s, a.tiles_per_wg);
