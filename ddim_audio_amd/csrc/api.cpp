@@ -20,11 +20,12 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles;
+    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);
         conv_wps = geti("DDIMX_CONV_WPS", 0);
+        gn_dbg = geti("DDIMX_GN_DBG", 0);  // A/B hook: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
@@ -284,7 +285,7 @@ struct Ws {
     void* A;                  // in-conv output (hidden[0])
     std::vector<void*> xd, xu;
     void *h1, *h2;
-    float *stats, *scale, *shift;
+    float *stats, *stats2, *scale, *shift;  // stats / stats2: the inference walk alternates (a kernel reads one, writes the other)
     float *ln0, *X, *Ut, *Z, *Y, *Hb, *O, *gpart;
     size_t total;
     size_t stats_per_sample, gpart_per_sample;  // floats: the statistics / split-K scratch one sample can need (max over ops)
@@ -314,7 +315,8 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
     const size_t lvl0 = (size_t)B * T * f.f_size * f.ch[0] * es;
     w->A = cv.take(lvl0);
     w->xd.resize(L); w->xu.resize(L);
-    size_t stats_f = (size_t)B * conv_in_nparts(T, f.f_size) * f.ch[0] * 2;
+    // per-channel slabs (training) and one 128-byte group slab per partial (inference, gn_fused.h): size for the larger
+    size_t stats_f = (size_t)B * conv_in_nparts(T, f.f_size) * (f.ch[0] * 2 > kGnSlab ? f.ch[0] * 2 : kGnSlab);
     size_t hmax = 0;
     int cmax = 0;
     for (int l = 0; l < L; ++l) {
@@ -326,7 +328,7 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
         if (C > cmax) cmax = C;
         size_t s = conv_stats_floats(c->dtype, CONV3, C, C, B, H, W);
         if (s > stats_f) stats_f = s;
-        s = (size_t)B * resid_nparts(c->dtype, H * W, C) * C * 2;
+        s = (size_t)B * resid_nparts(c->dtype, H * W, C) * (C * 2 > kGnSlab ? C * 2 : kGnSlab);
         if (s > stats_f) stats_f = s;
         if (l > 0) {
             s = conv_stats_floats(c->dtype, DOWN4, f.ch[l - 1], C, B, H, W);
@@ -341,6 +343,7 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
     w->h_per_sample = hmax / B;
     w->cmax = cmax;
     w->stats = (float*)cv.take(stats_f * 4);
+    w->stats2 = (float*)cv.take(stats_f * 4);  // (a conv's group slabs, 128 B per >= 32-channel workgroup, never exceed its per-channel ones)
     w->scale = (float*)cv.take((size_t)B * cmax * 4);
     w->shift = (float*)cv.take((size_t)B * cmax * 4);
     const int S = T >> (L - 1);
@@ -377,6 +380,8 @@ struct ConvCall {
     int B, Hin, Win;
     unsigned long long* stamps = nullptr;
     bool batch_plan = false;  // training: choose the tile variant from the real batch (inference: sample size only)
+    GnIn gn = {};             // gn.stats set: the input's GroupNorm is finished inside the kernel (in_scale / in_shift unused)
+    bool groups = false;      // statistics partials in group format (gn_fused.h)
 };
 
 // set for the duration of the whole-network training calls (see ConvCall::batch_plan)
@@ -397,6 +402,10 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     a.in = q.in; a.w = q.w; a.bias = q.bias; a.chan_add = q.chan_add; a.chan_add_stride = q.chan_add_stride;
     a.in_scale = q.in_scale; a.in_shift = q.in_shift; a.xf = q.xf; a.act = q.act;
     a.skip = q.skip; a.out = q.out; a.stats = q.stats;
+    a.gn = q.gn;
+    a.stats_groups_c = q.groups ? q.cout : 0;
+    if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
+    if (q.groups && q.cout % kGroups) return fail("conv: group-format statistics need cout %% 8 == 0");
     a.B = q.B; a.Hin = q.Hin; a.Win = q.Win;
     a.stamps = q.stamps;
     if (q.mode == DOWN4) {
@@ -423,7 +432,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         a.tiles_per_wg = cdiv(tiles_s, wps);
         a.wgs_per_sample = cdiv(tiles_s, a.tiles_per_wg);
     }
-    if (nparts) *nparts = a.wgs_per_sample * g.classes;
+    if (nparts) *nparts = a.wgs_per_sample * g.classes * (q.groups ? g.nout / g.nb : 1);
     if (Cs) *Cs = g.nout;
     HIPCHK(conv_launch(q.dtype, q.mode, q.cin, q.cout, var, a, s));
     return 0;
@@ -449,12 +458,43 @@ static inline size_t rb_tape_small_floats(int B, int C) { return (size_t)6 * B *
 // ([B][x_nparts][x_Cs][2]).  On return, if want_stats, `stats` holds those of y (*y_nparts, Cs = C).
 // tape != null: training forward -- the convs store their PRE-activation outputs (u1 = conv0 + temb, u2 = conv1 + bias)
 // in the tape and the consumers apply SiLU while loading; the result is the same function of the same inputs.
+// stats2 != null (inference walk, no tape): launch-free GroupNorm (gn_fused.h).  All partials are in group format
+// ([B][np][8][2], x_Cs unused), every consumer finishes its input's normalisation itself, and the two buffers alternate
+// because a kernel now reads its input's partials while it writes its output's: x in `stats` -> conv0 -> `stats2` ->
+// conv1 -> `stats` -> resid -> `stats2` = those of y (the caller swaps).  Samples with more than kGnFuseMaxParts partials
+// (long spectrograms, shallow levels) take one gn_finalize_groups launch instead, per GroupNorm.
 static int run_resblock(int dtype, int C, const void* x, void* y, const float* temb, int temb_stride, const RBPtrs& p,
                         void* h1, void* h2, float* stats, float* scale, float* shift, int x_nparts, int x_Cs,
-                        bool want_stats, int* y_nparts, int B, int H, int W, hipStream_t s, const RBTape* tape = nullptr) {
+                        bool want_stats, int* y_nparts, int B, int H, int W, hipStream_t s, const RBTape* tape = nullptr,
+                        float* stats2 = nullptr) {
     const double cnt = (double)H * W * (C / kGroups);
     const float eps = 1e-6f;
     int np = 0, cs = 0;
+    if (stats2) {
+        if (tape) return fail("run_resblock: the launch-free GroupNorm path keeps no tape");
+        // GroupNorm input of one consumer: in-kernel when the partials are few, else scale / shift from one launch
+        auto gn_of = [&](const float* st, int n, const float* gamma, const float* beta, GnIn* g, bool* fused, int which) -> int {
+            *g = GnIn{st, gamma, beta, 1.0 / cnt, eps, n};
+            *fused = n <= kGnFuseMaxParts;
+            if (!*fused || (knobs().gn_dbg & which)) HIPCHK(gn_finalize_groups_launch(*g, C, scale, shift, B, s));
+            return 0;
+        };
+        GnIn g; bool fu;
+        CHK(gn_of(stats, x_nparts, p.g0, p.b0, &g, &fu, 2));
+        ConvCall k1 = {dtype, CONV3, C, C, x, p.w0, nullptr, temb, temb_stride, scale, shift, XF_AFFINE_SILU, 1, nullptr, h1, stats2, B, H, W};
+        if (fu && !(knobs().gn_dbg & 2)) k1.gn = g;
+        k1.groups = true;
+        CHK(run_conv(k1, s, &np, &cs));
+        CHK(gn_of(stats2, np, p.g1, p.b1, &g, &fu, 2));
+        ConvCall k2 = {dtype, CONV3, C, C, h1, p.w1, p.bias1, nullptr, 0, scale, shift, XF_AFFINE, 1, nullptr, h2, stats, B, H, W};
+        if (fu && !(knobs().gn_dbg & 2)) k2.gn = g;
+        k2.groups = true;
+        CHK(run_conv(k2, s, &np, &cs));
+        CHK(gn_of(stats, np, p.g2, nullptr, &g, &fu, 1));
+        HIPCHK(resid_launch(dtype, x, h2, 0, scale, shift, y, want_stats ? stats2 : nullptr, B, H * W, C, s, (fu && !(knobs().gn_dbg & 1)) ? &g : nullptr, 1));
+        if (y_nparts) *y_nparts = resid_nparts(dtype, H * W, C);
+        return 0;
+    }
     float *sc0 = scale, *sh0 = shift, *sc1 = scale, *sh1 = shift, *sc2 = scale, *sh2 = shift;
     float *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;
     if (tape) {
@@ -790,7 +830,9 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     auto at = [&](const void* p, size_t per_sample, int b0) { return (void*)((char*)const_cast<void*>(p) + per_sample * b0); };
     // scratch shared by all levels (h1 / h2, statistics, scale / shift): a shard's share starts at b0 x (the most one sample
     // can need on ANY level) -- the two shards drift apart and may be on different levels at the same time
-    auto stats_of = [&](const Lane& ln) { return w.stats + w.stats_per_sample * ln.b0; };
+    // statistics partials (group format, gn_fused.h): buffer `cur` holds those of the tensor the next GroupNorm reads
+    int cur = 0;
+    auto stats_of = [&](const Lane& ln, int which) { return (which ? w.stats2 : w.stats) + w.stats_per_sample * ln.b0; };
     auto scale_of = [&](const Lane& ln) { return w.scale + (size_t)w.cmax * ln.b0; };
     auto shift_of = [&](const Lane& ln) { return w.shift + (size_t)w.cmax * ln.b0; };
 
@@ -806,8 +848,8 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
         return for_lanes(lvl_on(l), [&](const Lane& ln) -> int {
             return run_resblock(dt, C, at(in, act_bytes(l), ln.b0), at(out, act_bytes(l), ln.b0), temb_chunk + (size_t)c->E * ln.b0, c->E,
-                                rb_ptrs(c, packed, rbw), at(w.h1, w.h_per_sample, ln.b0), at(w.h2, w.h_per_sample, ln.b0), stats_of(ln),
-                                scale_of(ln), shift_of(ln), np, cs, want_stats, ynp, ln.n, H, W, ln.st);
+                                rb_ptrs(c, packed, rbw), at(w.h1, w.h_per_sample, ln.b0), at(w.h2, w.h_per_sample, ln.b0), stats_of(ln, cur),
+                                scale_of(ln), shift_of(ln), np, cs, want_stats, ynp, ln.n, H, W, ln.st, nullptr, stats_of(ln, cur ^ 1));
         });
     };
 
@@ -815,28 +857,31 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     const size_t in_per = (size_t)f.in_channels * T * f.f_size;  // fp32 NCHW elements per sample at the network boundary
     CHK(for_lanes(lvl_on(0), [&](const Lane& ln) -> int {
         HIPCHK(conv_in_launch(dt, x + in_per * ln.b0, pf(c, packed, c->in_w), pf(c, packed, c->in_b), at(w.A, act_bytes(0), ln.b0),
-                              stats_of(ln), ln.n, f.in_channels, f.ch[0], T, f.f_size, ln.st));
+                              stats_of(ln, 0), ln.n, f.in_channels, f.ch[0], T, f.f_size, ln.st, 1));
         return 0;
     }));
     int np = conv_in_nparts(T, f.f_size), cs = f.ch[0];
-    const void* cur = w.A;
+    const void* xcur = w.A;
     int bi = 0;
     for (int l = 0; l < L; ++l) {
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
         if (l > 0) {
             CHK(for_lanes(lvl_on(l), [&](const Lane& ln) -> int {
-                ConvCall d = {dt, DOWN4, f.ch[l - 1], C, at(cur, act_bytes(l - 1), ln.b0), pv(c, packed, c->down_w[l]),
+                ConvCall d = {dt, DOWN4, f.ch[l - 1], C, at(xcur, act_bytes(l - 1), ln.b0), pv(c, packed, c->down_w[l]),
                               pf(c, packed, c->down_b[l]), nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr,
-                              at(w.xd[l], act_bytes(l), ln.b0), stats_of(ln), ln.n, H * 2, W * 2};
+                              at(w.xd[l], act_bytes(l), ln.b0), stats_of(ln, 0), ln.n, H * 2, W * 2};
+                d.groups = true;
                 return run_conv(d, ln.st, &np, &cs);
             }));
-            cur = w.xd[l];
+            cur = 0;
+            xcur = w.xd[l];
         }
         for (int r = 0; r < f.res[l]; ++r, ++bi) {
             const bool last = (r == f.res[l] - 1);
             int ynp = 0;
-            CHK(resblock(l, cur, w.xd[l], w.temb + c->emb_off_down[bi], c->down_rb[l][r], np, cs, !last, &ynp));
-            cur = w.xd[l];
+            CHK(resblock(l, xcur, w.xd[l], w.temb + c->emb_off_down[bi], c->down_rb[l][r], np, cs, !last, &ynp));
+            xcur = w.xd[l];
+            cur ^= 1;
             np = ynp; cs = C;
         }
         if (f.res[l] == 0 && l == 0) return fail("level 0 needs at least one residual block");
@@ -854,9 +899,10 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     }));
     CHK(for_lanes(lvl_on(L - 1), [&](const Lane& ln) -> int {
         HIPCHK(resid_launch(dt, at(w.xd[L - 1], act_bytes(L - 1), ln.b0), w.O + (size_t)ln.b0 * S * c->width, 1, nullptr, nullptr,
-                            at(w.xu[L - 1], act_bytes(L - 1), ln.b0), stats_of(ln), ln.n, S * c->Fr, CL, ln.st));
+                            at(w.xu[L - 1], act_bytes(L - 1), ln.b0), stats_of(ln, 0), ln.n, S * c->Fr, CL, ln.st, nullptr, 1));
         return 0;
     }));
+    cur = 0;
     np = resid_nparts(dt, S * c->Fr, CL); cs = CL;
     // ---- up path (models/diffusion.py:281-292) ----
     bi = 0;
@@ -866,15 +912,18 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
             const bool last = (r == f.res[l] - 1);
             int ynp = 0;
             CHK(resblock(l, w.xu[l], w.xu[l], w.temb + c->emb_off_up[bi], c->up_rb[l][r], np, cs, !last, &ynp));
+            cur ^= 1;
             np = ynp; cs = C;
         }
         if (l > 0) {
             CHK(for_lanes(lvl_on(l - 1), [&](const Lane& ln) -> int {
                 ConvCall u = {dt, UP4, C, f.ch[l - 1], at(w.xu[l], act_bytes(l), ln.b0), pv(c, packed, c->up_w[l]), pf(c, packed, c->up_b[l]),
                               nullptr, 0, nullptr, nullptr, XF_NONE, 0, at(w.xd[l - 1], act_bytes(l - 1), ln.b0),
-                              at(w.xu[l - 1], act_bytes(l - 1), ln.b0), stats_of(ln), ln.n, H, W};
+                              at(w.xu[l - 1], act_bytes(l - 1), ln.b0), stats_of(ln, 0), ln.n, H, W};
+                u.groups = true;
                 return run_conv(u, ln.st, &np, &cs);
             }));
+            cur = 0;
         }
     }
     CHK(for_lanes(lvl_on(0), [&](const Lane& ln) -> int {
@@ -1506,16 +1555,17 @@ int ddimx_pack_convT(int dtype, const float* w, void* dst, int I, int O, void* s
     return 0;
 }
 
-struct OpWs { void *h1, *h2; float *stats, *scale, *shift; size_t total; };
+struct OpWs { void *h1, *h2; float *stats, *stats2, *scale, *shift; size_t total; };
 static void carve_op(char* base, int dtype, int B, int C, int H, int W, OpWs* o) {
     Carver cv{base, 0};
     const size_t act = (size_t)B * H * W * C * esz(dtype);
     o->h1 = cv.take(act);
     o->h2 = cv.take(act);
     size_t sf = conv_stats_floats(dtype, CONV3, C, C, B, H, W);
-    const size_t s2 = (size_t)B * resid_nparts(dtype, H * W, C) * C * 2;
+    const size_t s2 = (size_t)B * resid_nparts(dtype, H * W, C) * (C * 2 > kGnSlab ? C * 2 : kGnSlab);
     if (s2 > sf) sf = s2;
     o->stats = (float*)cv.take(sf * 4);
+    o->stats2 = (float*)cv.take(sf * 4);
     o->scale = (float*)cv.take((size_t)B * C * 4);
     o->shift = (float*)cv.take((size_t)B * C * 4);
     o->total = cv.off;
@@ -1533,10 +1583,10 @@ int ddimx_resblock_fwd(int dtype, int C, const void* x, void* y, const float* te
     hipStream_t s = (hipStream_t)stream;
     OpWs o;
     carve_op((char*)workspace, dtype, B, C, H, W, &o);
-    HIPCHK(tensor_stats_launch(dtype, x, o.stats, B, H * W, C, s));
+    HIPCHK(tensor_stats_launch(dtype, x, o.stats, B, H * W, C, s, 1));
     RBPtrs p = {gn0_w, gn0_b, gn1_w, gn1_b, gn2_w, bias1, w0, w1};
     return run_resblock(dtype, C, x, y, temb, temb_stride, p, o.h1, o.h2, o.stats, o.scale, o.shift,
-                        resid_nparts(dtype, H * W, C), C, false, nullptr, B, H, W, s);
+                        resid_nparts(dtype, H * W, C), C, false, nullptr, B, H, W, s, nullptr, o.stats2);
 }
 // ---- training: Residual_Block forward that keeps its tape, and its backward --------------------------
 long long ddimx_rb_tape_floats(int B, int C) { return (long long)rb_tape_small_floats(B, C); }

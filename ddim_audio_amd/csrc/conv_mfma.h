@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gn_fused.h"
 
 namespace ddimx {
 
@@ -43,7 +44,11 @@ struct ConvArgs {
     const float* in_shift;  // [B][CIN]
     const void* skip;       // same shape as out, added in the epilogue, or null
     void* out;              // [B][Hout][Wout][COUT]
-    float* stats;           // [B][nparts][NOUT][2] partial (sum, sumsq) or null
+    float* stats;           // [B][nparts][NOUT][2] partial (sum, sumsq) or null; with stats_groups_c > 0 instead
+                            // [B][nparts * NOUT/NB][kGroups][2]: the workgroup's partials folded to the 8 groups (gn_fused.h)
+    int stats_groups_c;     // 0, or the real channel count of the output (NOUT / column classes)
+    GnIn gn;                // gn.stats != null (and xf != XF_NONE): scale / shift come from the input's group partials,
+                            // finished by every workgroup in its prologue, instead of in_scale / in_shift
     int chan_add_stride;
     int xf;                 // XF_*
     int act;                // 0 none, 1 SiLU, 2 store the pre-activation but take the statistics of SiLU(value) (training)
@@ -92,7 +97,7 @@ struct ConvCfg {
     static constexpr int DMA_PER_WAVE = (DMA_INSTR + NWAVES - 1) / NWAVES;
     static constexpr int WSTAGE_BYTES = DMA_INSTR * 1024;  // surplus DMA slots of the last round go to a dummy KiB
     static constexpr int NSTAGE = 3;
-    static constexpr int WBUF_BYTES = NCHUNKS > 1 ? NSTAGE * WSTAGE_BYTES + 1024 : WCHUNK_BYTES;
+    static constexpr int WBUF_BYTES = (NCHUNKS > 1 ? NSTAGE : 1) * WSTAGE_BYTES + 1024;
     static constexpr int RED_BYTES = NWAVES * NB * 2 * 4;  // per-wave per-channel (sum, sumsq); overlays wbuf/halo at the end
     static constexpr bool RESIDENT_W = NCHUNKS == 1;       // all taps in one chunk: loaded once per workgroup
     // the epilogue's output tile gets its own LDS region when everything fits in 80 KiB (2 workgroups per CU);
@@ -101,7 +106,8 @@ struct ConvCfg {
     static constexpr bool SEPARATE_OUT = OVL_ == 2 || (OVL_ == 0 && WBUF_BYTES + HALO_BYTES + OUT_BYTES <= 80 * 1024);
     static constexpr int HO_BYTES = SEPARATE_OUT ? HALO_BYTES + OUT_BYTES : (HALO_BYTES > OUT_BYTES ? HALO_BYTES : OUT_BYTES);
     static constexpr int ADD_BYTES = NB * 4;  // per-cout epilogue addend (bias + timestep embedding) of this sample
-    static constexpr int LDS_RAW = ADD_BYTES + WBUF_BYTES + HO_BYTES;
+    static constexpr int GN_BYTES = NWAVES * kGroups * 2 * 4;  // per-wave (sum, sumsq) per group (gn_fused.h); behind the rest
+    static constexpr int LDS_RAW = ADD_BYTES + WBUF_BYTES + HO_BYTES + GN_BYTES;
     static constexpr int LDS_BYTES = LDS_RAW > RED_BYTES ? LDS_RAW : RED_BYTES;
     static constexpr int KG = KC * ES / 32;  // 32-byte k-groups per tap per chunk
     static constexpr int WPIECES = TPC * NB * (KC / EPB);
@@ -161,35 +167,6 @@ template <> struct Mma<float> {
 };
 
 
-template <class C>
-__device__ __forceinline__ void conv_w_load(uint4 (&wreg)[C::WPT], const typename C::elem* wbase, int cout0, int tid,
-                                            int ch) {
-    const int tap0 = (ch / C::KSPLIT) * C::TPC;
-    const int kc0 = (ch % C::KSPLIT) * C::KC;
-    constexpr int PPR = C::KC / C::EPB;  // 16-B pieces per weight row
-#pragma unroll
-    for (int i = 0; i < C::WPT; ++i) {
-        const int pc = tid + i * C::NTHREADS;
-        wreg[i] = make_uint4(0, 0, 0, 0);
-        if (pc < C::WPIECES) {
-            const int j = pc % PPR, row = (pc / PPR) % C::NB, tp = pc / (PPR * C::NB);
-            wreg[i] = *(const uint4*)(wbase + ((size_t)(tap0 + tp) * C::NOUT + cout0 + row) * C::CIN + kc0 + j * C::EPB);
-        }
-    }
-}
-template <class C>
-__device__ __forceinline__ void conv_w_store(const uint4 (&wreg)[C::WPT], char* dst, int tid) {
-    constexpr int PPR = C::KC / C::EPB;
-#pragma unroll
-    for (int i = 0; i < C::WPT; ++i) {
-        const int pc = tid + i * C::NTHREADS;
-        if (pc < C::WPIECES) {
-            const int j = pc % PPR, row = (pc / PPR) % C::NB, tp = pc / (PPR * C::NB);
-            *(uint4*)(dst + (tp * C::NB + row) * C::WROW + j * 16) = wreg[i];
-        }
-    }
-}
-
 // In-kernel phase stamps (diagnostic build libddimx_stamp.so only; the product library never executes one).
 #ifdef DDIMX_STAMP
 #define DDIMX_STAMP_DECL unsigned long long st_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, st_last = 0; { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); }
@@ -210,6 +187,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     char* const wbuf = smem + C::ADD_BYTES;
     char* const halo = wbuf + C::WBUF_BYTES;
     char* const otile = C::SEPARATE_OUT ? halo + C::HALO_BYTES : halo;
+    float* const gnscr = (float*)(smem + C::LDS_RAW - C::GN_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % C::WM, wn = wave / C::WM;
@@ -234,14 +212,13 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
 
     const T* const wbase = (const T*)a.w + (size_t)cls * C::NTAPS * NOUT * CIN;
 
-    // ---- weights.  Resident (all taps in one chunk): loaded once through registers.  Streaming: a 3-stage
-    // LDS-DMA ring that runs continuously across tiles -- while chunk g is multiplied, chunk g+1 is landing and
-    // chunk g+2 is being issued; no VGPRs are spent on staging.  Per-lane source offsets (relative to the
-    // chunk base) are tile- and chunk-invariant and hoisted here; the LDS destination of DMA instruction q is
-    // stage_base + q * 1 KiB (wave-uniform), lanes that map to row padding re-read the chunk base.
-    uint4 wregA[C::RESIDENT_W ? C::WPT : 1];
-    unsigned wrel[C::RESIDENT_W ? 1 : C::DMA_PER_WAVE];
-    if constexpr (!C::RESIDENT_W) {
+    // ---- weights: LDS-DMA, no VGPRs spent on staging.  Resident (all taps in one chunk): one chunk, issued once in the
+    // prologue.  Streaming: a 3-stage ring that runs continuously across tiles -- while chunk g is multiplied, chunk g+1 is
+    // landing and chunk g+2 is being issued.  Per-lane source offsets (relative to the chunk base) are tile- and chunk-
+    // invariant and hoisted here; the LDS destination of DMA instruction q is stage_base + q * 1 KiB (wave-uniform),
+    // lanes that map to row padding re-read the chunk base.
+    unsigned wrel[C::DMA_PER_WAVE];
+    {
 #pragma unroll
         for (int j = 0; j < C::DMA_PER_WAVE; ++j) {
             const int idx = (wave + j * C::NWAVES) * 64 + lane;
@@ -255,9 +232,9 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     // not provably uniform to the compiler)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned wbuf_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wbuf) + (unsigned)wave_u * 1024u);
-    const unsigned wdummy_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wbuf) + (unsigned)(C::NSTAGE * C::WSTAGE_BYTES));
+    const unsigned wdummy_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wbuf) + (unsigned)(C::WBUF_BYTES - 1024));
     auto dma_issue = [&](int ch, int stage) __attribute__((always_inline)) {
-        if constexpr (!C::RESIDENT_W) {
+        {
             const int tap0 = (ch / C::KSPLIT) * C::TPC, kc0 = (ch % C::KSPLIT) * C::KC;
             const char* cbase = (const char*)(wbase + ((size_t)tap0 * NOUT + cout0) * CIN + kc0);
             const unsigned dst0 = wbuf_lds + stage * C::WSTAGE_BYTES;
@@ -278,13 +255,6 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     f32x2_t sc[NP], sh[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
-    if (a.xf != XF_NONE && hvalid) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            sc[j] = *(const f32x2_t*)(a.in_scale + (size_t)bs * CIN + hc * EPB + 2 * j);
-            sh[j] = *(const f32x2_t*)(a.in_shift + (size_t)bs * CIN + hc * EPB + 2 * j);
-        }
-    }
     // per-sample buffer resources (wave-uniform: built from kernel arguments and blockIdx only)
     const unsigned in_bytes = (unsigned)((size_t)a.Hin * a.Win * CIN * ES);
     const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc((const T*)a.in + (size_t)bs * a.Hin * a.Win * CIN, in_bytes);
@@ -366,10 +336,11 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
         }
     };
     // write tile t's halo to LDS (from the prefetch registers, or loading it now)
-    auto halo_commit_xf = [&](auto xf_tag, int t) __attribute__((always_inline)) {
+    // pre: the tile's pieces are already in hreg (prefetch configurations always; the first tile of a hoisted one)
+    auto halo_commit_xf = [&](auto xf_tag, int t, bool pre) __attribute__((always_inline)) {
         if (!hvalid) return;  // lanes beyond the channel pieces of a pixel (C/8 not a power of two)
         if constexpr (C::HOIST) {
-            if constexpr (!C::PREFETCH) halo_load_all(t);
+            if (!C::PREFETCH && !pre) halo_load_all(t);
             if (hok == 0xFFFFFFFFu) {  // interior tile: every piece is real data
 #pragma unroll
                 for (int i = 0; i < C::HPT; ++i)
@@ -391,11 +362,11 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
             }
         }
     };
-    auto halo_commit = [&](int t) __attribute__((always_inline)) {
-        if (a.xf == XF_AFFINE_SILU) halo_commit_xf(std::integral_constant<int, XF_AFFINE_SILU>(), t);
-        else if (a.xf == XF_SILU_AFFINE) halo_commit_xf(std::integral_constant<int, XF_SILU_AFFINE>(), t);
-        else if (a.xf == XF_AFFINE) halo_commit_xf(std::integral_constant<int, XF_AFFINE>(), t);
-        else halo_commit_xf(std::integral_constant<int, XF_NONE>(), t);
+    auto halo_commit = [&](int t, bool pre = false) __attribute__((always_inline)) {
+        if (a.xf == XF_AFFINE_SILU) halo_commit_xf(std::integral_constant<int, XF_AFFINE_SILU>(), t, pre);
+        else if (a.xf == XF_SILU_AFFINE) halo_commit_xf(std::integral_constant<int, XF_SILU_AFFINE>(), t, pre);
+        else if (a.xf == XF_AFFINE) halo_commit_xf(std::integral_constant<int, XF_AFFINE>(), t, pre);
+        else halo_commit_xf(std::integral_constant<int, XF_NONE>(), t, pre);
     };
 
     // ---- per-lane MFMA operand offsets (tile independent) ----------------------------------------------
@@ -421,21 +392,88 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
 
     // ---- prologue: resident weights (if they fit in one chunk) and the first halo ------------------------
     int wstage = 0;  // ring stage holding the chunk about to be multiplied
-    if constexpr (C::RESIDENT_W) {
-        conv_w_load<C>(wregA, wbase, cout0, tid, 0);
-        conv_w_store<C>(wregA, wbuf, tid);
-    } else {
-        dma_issue(0, 0);
-        dma_issue(1 % C::NCHUNKS, 1);
+    // Order of issue: (GroupNorm partials, above) -> weights -> the first tile's halo -> then the first wait.  Hoisted
+    // configurations keep all halo pieces of a tile in registers, so the first tile's loads overlap the weights and the
+    // partials instead of following them.
+    // (All loads of the prologue are issued here, after every address computation above: a load issued earlier can stall
+    // unrelated integer code through a register pair the allocator happens to share with its destination.  The scheduling
+    // barrier and the empty asm statements (which "use" the hoisted offsets) keep that code from sinking below the loads.)
+    if constexpr (C::HOIST) {
+#pragma unroll
+        for (int i = 0; i < C::HPT; ++i) asm volatile("" ::"v"(hrel[i]), "v"(hlds[i]) : "memory");
     }
-    for (int i = tid; i < NB; i += C::NTHREADS) {
-        float v = 0.f;
-        if (a.bias) v += a.bias[cout0 + i];
-        if (a.chan_add) v += a.chan_add[(size_t)bs * a.chan_add_stride + cout0 + i];
-        addv[i] = v;
+#pragma unroll
+    for (int j = 0; j < C::DMA_PER_WAVE; ++j) asm volatile("" ::"v"(wrel[j]) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // per-cout epilogue addend (bias + this sample's timestep-embedding slice): loaded first and without branches (absent
+    // operands read a valid dummy address and are dropped by a select), stored to LDS once everything else is in flight
+    constexpr int AIT = (NB + C::NTHREADS - 1) / C::NTHREADS;
+    float add_b[AIT], add_c[AIT];
+    {
+        const float* pb = a.bias ? a.bias + cout0 : (const float*)a.w;
+        const float* pc = a.chan_add ? a.chan_add + (size_t)bs * a.chan_add_stride + cout0 : (const float*)a.w;
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int i = tid + k * C::NTHREADS;
+            const int ic = i < NB ? i : NB - 1;
+            add_b[k] = pb[ic];
+            add_c[k] = pc[ic];
+        }
     }
-    halo_issue(t_begin);
-    halo_commit(t_begin);
+    // consumer-side GroupNorm finalisation (gn_fused.h): this sample's group partials are summed first -- their loads are the
+    // oldest in the queue, the weight and halo loads below overlap the reduction
+    const bool gn_fused = a.xf != XF_NONE && a.gn.stats != nullptr;  // uniform
+    GnInLoads gn_ld;
+    if (gn_fused) gn_in_issue(a.gn, bs, tid, C::NTHREADS, gn_ld);
+
+    // one load sequence for both sources (a second, branch-separated one made the compiler wait for every load in flight at
+    // the merge): folded (scale, shift) of this sample, or -- consumer-side finalisation -- (gamma, beta) to be folded with
+    // the group statistics after the reduction below.  beta == null: gamma is read in its place and dropped.
+    if (a.xf != XF_NONE && hvalid) {
+        const float* psc = gn_fused ? a.gn.gamma + hc * EPB : a.in_scale + (size_t)bs * CIN + hc * EPB;
+        const float* psh = gn_fused ? (a.gn.beta ? a.gn.beta : a.gn.gamma) + hc * EPB : a.in_shift + (size_t)bs * CIN + hc * EPB;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            sc[j] = *(const f32x2_t*)(psc + 2 * j);
+            sh[j] = *(const f32x2_t*)(psh + 2 * j);
+        }
+    }
+    dma_issue(0, 0);
+    if constexpr (!C::RESIDENT_W) dma_issue(1 % C::NCHUNKS, 1);
+    if constexpr (C::PREFETCH) {
+        halo_issue(t_begin);
+    } else if constexpr (C::HOIST) {
+        halo_load_all(t_begin);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < AIT; ++k) {
+        const int i = tid + k * C::NTHREADS;
+        if (i < NB) addv[i] = (a.bias ? add_b[k] : 0.f) + (a.chan_add ? add_c[k] : 0.f);
+    }
+    if (gn_fused) {
+        gn_in_reduce(a.gn, bs, tid, C::NTHREADS, gn_ld, gnscr);
+        __syncthreads();  // the waves' group sums are in gnscr
+        if (hvalid) {
+            float gam[EPB], bet[EPB], fs[EPB], fh[EPB];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                gam[2 * j] = sc[j].x; gam[2 * j + 1] = sc[j].y;
+                bet[2 * j] = a.gn.beta ? sh[j].x : 0.f; bet[2 * j + 1] = a.gn.beta ? sh[j].y : 0.f;
+            }
+            gn_in_fold<EPB>(a.gn, gnscr, C::NWAVES, CIN, hc * EPB, gam, bet, fs, fh);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                sc[j].x = fs[2 * j]; sc[j].y = fs[2 * j + 1];
+                sh[j].x = fh[2 * j]; sh[j].y = fh[2 * j + 1];
+            }
+        }
+    }
+    halo_commit(t_begin, C::HOIST);
+    // resident weights: the chunk must have landed before the first MFMA (LDS-DMA is inline asm, invisible to the
+    // compiler's waitcnt insertion; the streamed ring has its own counted waits)
+    if constexpr (C::RESIDENT_W) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     DDIMX_STAMP_DECL
 
@@ -639,11 +677,17 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
         __syncthreads();
         const int nparts = a.wgs_per_sample * gridDim.z;
         const int part = wg * gridDim.z + cls;
-        for (int i = tid; i < NB * 2; i += C::NTHREADS) {
-            float t = 0.f;
+        if (a.stats_groups_c) {  // uniform: group format -- wave 0 folds the waves' channel sums straight into the 8 bins
+            if (wave == 0)
+                gn_bins_store<C::NWAVES>(red, NB * 2, NB, cout0, a.stats_groups_c,
+                              a.stats + (((size_t)bs * nparts + part) * gridDim.y + blockIdx.y) * kGnSlab, lane);
+        } else {
+            for (int i = tid; i < NB * 2; i += C::NTHREADS) {
+                float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < C::NWAVES; ++w) t += red[w * NB * 2 + i];
-            a.stats[(((size_t)bs * nparts + part) * NOUT + cout0) * 2 + i] = t;
+                for (int w = 0; w < C::NWAVES; ++w) t += red[w * NB * 2 + i];
+                a.stats[(((size_t)bs * nparts + part) * NOUT + cout0) * 2 + i] = t;
+            }
         }
     }
 }

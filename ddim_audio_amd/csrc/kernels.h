@@ -2,13 +2,15 @@
 // All enqueue on the given stream, never allocate or synchronise (graph-capturable).
 #pragma once
 #include "common.h"
+#include "gn_fused.h"
 
 namespace ddimx {
 
 // ---- U-Net edge convolutions (C_io = 2 side; HBM-bound; layout conversion NCHW fp32 <-> NHWC T) ----
 // in-conv: reference models/diffusion.py:189-198.  x [B][2][H][W] fp32 -> out [B][H][W][C0] T, + stats partials
 hipError_t conv_in_launch(int dtype, const float* x, const float* w /*[C0][cin][3][3]*/, const float* bias, void* out,
-                          float* stats, int B, int cin, int C0, int H, int W, hipStream_t s);
+                          float* stats, int B, int cin, int C0, int H, int W, hipStream_t s, int groups = 0);
+// groups = 1 (here and below): the statistics partials are written folded to the 8 groups, [B][nparts][8][2] (gn_fused.h)
 int conv_in_nparts(int H, int W);
 // out-conv: models/diffusion.py:199-208 preceded by x + hidden[0] (:284).  (a + b) NHWC T -> eps [B][cout][H][W] fp32
 hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float* w /*packed [9][cout][C0] fp32*/,
@@ -19,15 +21,19 @@ hipError_t conv_out_launch(int dtype, const void* a, const void* b, const float*
 hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, double count, const float* gamma,
                               const float* beta /*nullable*/, float eps, float* scale, float* shift, int B,
                               hipStream_t s, float* mean_rstd_out /*[B][8][2], nullable*/ = nullptr);
+// the same from group-format partials (gn.stats [B][gn.np][8][2])
+hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float* shift, int B, hipStream_t s);
 
 // ---- residual pass: y = x + (h*scale + shift)  (block tail, models/diffusion.py:54-56), or y = x + h ----
 // h_f32 = 1: h is fp32 (FNet output) and no affine is applied; h_f32 = 2: y = x + SiLU(h)*scale + shift (training
 // forward, h = pre-activation).  stats nullable.  Elements per sample = HW*C.
+// gn != null (gn->stats set): scale / shift are derived in-kernel from the group partials of h (consumer-side finalisation)
 hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, const float* scale, const float* shift,
-                        void* y, float* stats, int B, int HW, int C, hipStream_t s);
+                        void* y, float* stats, int B, int HW, int C, hipStream_t s, const GnIn* gn = nullptr, int groups = 0);
 int resid_nparts(int dtype, int HW, int C);
+int resid_iters(int dtype, int HW, int C);  // 16-byte pieces per thread of the element-wise passes (sample size only)
 // per-channel (sum, sumsq) partials of an NHWC tensor, same partitioning as resid_nparts
-hipError_t tensor_stats_launch(int dtype, const void* x, float* stats, int B, int HW, int C, hipStream_t s);
+hipError_t tensor_stats_launch(int dtype, const void* x, float* stats, int B, int HW, int C, hipStream_t s, int groups = 0);
 hipError_t to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int HW, hipStream_t s);
 hipError_t from_nhwc_launch(int dtype, const void* in, float* out, int B, int C, int HW, hipStream_t s);
 

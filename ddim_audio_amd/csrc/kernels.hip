@@ -2,6 +2,7 @@
 // pass, small dense layers, LayerNorm, sampler / loss / EMA elementwise kernels and weight packing.
 // gfx950 only.  Every reduction is a fixed-order tree (no float atomics): results are reproducible.
 #include "kernels.h"
+#include "gn_fused.h"
 
 namespace ddimx {
 
@@ -14,7 +15,8 @@ int conv_in_nparts(int H, int W) { return (H * W + kInPixPerBlock - 1) / kInPixP
 template <typename T>
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, T* __restrict__ out,
-                                                      float* __restrict__ stats, int cin, int C0, int H, int W) {
+                                                      float* __restrict__ stats, int cin, int C0, int H, int W,
+                                                      int groups) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                       // [cin*9][C0]
@@ -70,9 +72,13 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
             }
         }
         __syncthreads();
-        for (int i = tid; i < C0 * 2; i += 256) {
-            const float t = red[i] + red[C0 * 2 + i] + red[2 * C0 * 2 + i] + red[3 * C0 * 2 + i];
-            stats[(((size_t)b * gridDim.x + part) * C0) * 2 + i] = t;
+        if (groups) {  // group-format partials (gn_fused.h)
+            if (wave == 0) gn_bins_store<4>(red, C0 * 2, C0, 0, C0, stats + ((size_t)b * gridDim.x + part) * kGnSlab, lane);
+        } else {
+            for (int i = tid; i < C0 * 2; i += 256) {
+                const float t = red[i] + red[C0 * 2 + i] + red[2 * C0 * 2 + i] + red[3 * C0 * 2 + i];
+                stats[(((size_t)b * gridDim.x + part) * C0) * 2 + i] = t;
+            }
         }
     }
 }
@@ -83,10 +89,10 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
 template <typename T, int C0, int CIN>
 __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, T* __restrict__ out,
-                                                           float* __restrict__ stats, int H, int W) {
+                                                           float* __restrict__ stats, int H, int W, int groups) {
     constexpr int EPB = Piece<T>::N;
     constexpr int ROWB = C0 * (int)sizeof(T), PCS = ROWB / 16;  // bytes / 16-byte pieces per pixel
-    __shared__ float red[4][C0 * 2];
+    __shared__ float red[4][C0 * 2];  // per-wave (sum, sumsq) per channel
     // per-wave staging tile: a lane computes one pixel (ROWB contiguous bytes), but a store instruction should write
     // contiguous memory across the lanes -> pieces go through LDS (row stride ROWB + 16 keeps the b128 accesses conflict-free)
     __shared__ __attribute__((aligned(16))) char otile[4][64 * (ROWB + 16)];
@@ -153,29 +159,32 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
             if (lane == 0) { red[wave][c * 2] = ts; red[wave][c * 2 + 1] = tq; }
         }
         __syncthreads();
-        if (tid < C0 * 2)
+        if (groups) {  // group-format partials (gn_fused.h)
+            if (wave == 0) gn_bins_store<4>(&red[0][0], C0 * 2, C0, 0, C0, stats + ((size_t)b * gridDim.x + part) * kGnSlab, lane);
+        } else if (tid < C0 * 2) {
             stats[(((size_t)b * gridDim.x + part) * C0) * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        }
     }
 }
 
 hipError_t conv_in_launch(int dtype, const float* x, const float* w, const float* bias, void* out, float* stats, int B,
-                          int cin, int C0, int H, int W, hipStream_t s) {
+                          int cin, int C0, int H, int W, hipStream_t s, int groups) {
     const int epb = dtype == DT_BF16 ? 8 : 4;
     const int opp = C0 / epb;
-    if (C0 % epb || opp > 64 || (opp & (opp - 1))) return hipErrorInvalidValue;
+    if (C0 % epb || opp > 64 || (opp & (opp - 1)) || (groups && C0 % kGroups)) return hipErrorInvalidValue;
     dim3 grid(conv_in_nparts(H, W), B);
     if (C0 == 32 && cin == 2) {
         if (dtype == DT_BF16)
-            hipLaunchKernelGGL((conv_in_fast_kernel<__bf16, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (__bf16*)out, stats, H, W);
+            hipLaunchKernelGGL((conv_in_fast_kernel<__bf16, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (__bf16*)out, stats, H, W, groups);
         else
-            hipLaunchKernelGGL((conv_in_fast_kernel<float, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (float*)out, stats, H, W);
+            hipLaunchKernelGGL((conv_in_fast_kernel<float, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (float*)out, stats, H, W, groups);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(cin * 9 * C0 + 4 * C0 * 2) * 4;
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL(conv_in_kernel<__bf16>, grid, dim3(256), lds, s, x, w, bias, (__bf16*)out, stats, cin, C0, H, W);
+        hipLaunchKernelGGL(conv_in_kernel<__bf16>, grid, dim3(256), lds, s, x, w, bias, (__bf16*)out, stats, cin, C0, H, W, groups);
     else
-        hipLaunchKernelGGL(conv_in_kernel<float>, grid, dim3(256), lds, s, x, w, bias, (float*)out, stats, cin, C0, H, W);
+        hipLaunchKernelGGL(conv_in_kernel<float>, grid, dim3(256), lds, s, x, w, bias, (float*)out, stats, cin, C0, H, W, groups);
     return hipGetLastError();
 }
 
@@ -377,23 +386,61 @@ hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, dou
     return hipGetLastError();
 }
 
+// The same from group-format partials (gn_fused.h) -- used where a sample has more than kGnFuseMaxParts partials (long
+// spectrograms at the shallow levels), so that consumers need not re-read them per workgroup.  One block per sample.
+__global__ void __launch_bounds__(256) gn_finalize_groups_kernel(const GnIn gn, int C, float* __restrict__ scale,
+                                                                 float* __restrict__ shift) {
+    __shared__ float scr[4 * kGroups * 2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    GnInLoads ld;
+    gn_in_issue(gn, b, tid, 256, ld);
+    gn_in_reduce(gn, b, tid, 256, ld, scr);
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float m, r;
+        gn_in_group(gn, scr, 4, c / (C / kGroups), &m, &r);
+        const float sc = r * gn.gamma[c];
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = (gn.beta ? gn.beta[c] : 0.f) - m * sc;
+    }
+}
+hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float* shift, int B, hipStream_t s) {
+    if (C % kGroups) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(B), dim3(256), 0, s, gn, C, scale, shift);
+    return hipGetLastError();
+}
+
 // =====================================================================================================
 // residual pass: y = x + (h*scale + shift)   or   y = x + h(fp32)
 // =====================================================================================================
-constexpr int kResidIters = 16;
+constexpr int kResidIters = 16;  // at most: 16-byte pieces per thread
 static inline int resid_bd(int cpp) { return (cpp % 3 == 0) ? 192 : 256; }
+// Pieces per thread of the element-wise passes over one sample (resid, tensor_stats, the GroupNorm-backward passes):
+// 16 where the sample is large, fewer on the deep levels so that a sample still spreads over >= 64 workgroups -- with 16
+// the level-5 tensor (8 192 pieces) was two workgroups per sample, each a chain of 16 dependent load round trips.
+// A function of the sample's size only (never of the batch): a sample's partial sums do not depend on the batch it is in.
+int resid_iters(int dtype, int HW, int C) {
+    const int epb = dtype == DT_BF16 ? 8 : 4;
+    const int cpp = C / epb;
+    const long long pieces = (long long)HW * cpp;
+    long long it = pieces / ((long long)resid_bd(cpp) * 64);
+    if (it < 1) it = 1;
+    if (it > kResidIters) it = kResidIters;
+    return (int)it;
+}
 int resid_nparts(int dtype, int HW, int C) {
     const int epb = dtype == DT_BF16 ? 8 : 4;
     const int cpp = C / epb;
     const long long pieces = (long long)HW * cpp;
-    const int per_block = resid_bd(cpp) * kResidIters;
+    const int per_block = resid_bd(cpp) * resid_iters(dtype, HW, C);
     return (int)((pieces + per_block - 1) / per_block);
 }
 
+// LDS: [R][C*2] per-row channel sums | [C*2] workgroup totals | [4 waves][8][2] floats (fused GroupNorm input)
 template <typename T, bool HF32, bool HSILU = false>
 __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __restrict__ hv,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    T* y, float* __restrict__ stats, int HW, int C) {
+                                                    T* y, float* __restrict__ stats, int HW, int C, const GnIn gn, int groups, int iters) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [R][C*2]
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -401,29 +448,33 @@ __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __re
     const int c = tid % CPP;
     const int b = blockIdx.y, part = blockIdx.x;
     const long long pieces = (long long)HW * CPP;
+    float* const scr = red + (bd / CPP) * C * 2 + C * 2;
     float sc[EPB], sh[EPB], s[EPB], q[EPB];
 #pragma unroll
-    for (int j = 0; j < EPB; ++j) {
-        s[j] = q[j] = 0.f;
-        sc[j] = HF32 ? 1.f : scale[(size_t)b * C + c * EPB + j];
-        sh[j] = HF32 ? 0.f : shift[(size_t)b * C + c * EPB + j];
-    }
+    for (int j = 0; j < EPB; ++j) { s[j] = q[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
+    // one 16-byte piece of x and of h per thread and iteration
+    constexpr int HN = HF32 ? EPB / 4 : 1;
     const size_t sbase = (size_t)b * HW * C;
-    for (int it = 0; it < kResidIters; ++it) {
-        const long long pc = ((long long)part * kResidIters + it) * bd + tid;
-        if (pc >= pieces) break;
-        const size_t e = sbase + (size_t)pc * EPB;
-        float fx[EPB], fh[EPB];
-        Piece<T>::unpack(*(const uint4*)(x + e), fx);
+    auto load = [&](size_t e, uint4& vx, uint4 (&vh)[HN]) __attribute__((always_inline)) {
+        vx = *(const uint4*)(x + e);
         if constexpr (HF32) {
-            const float* hp = (const float*)hv + e;
 #pragma unroll
-            for (int j = 0; j < EPB; j += 4) {
-                const float4 t = *(const float4*)(hp + j);
-                fh[j] = t.x; fh[j + 1] = t.y; fh[j + 2] = t.z; fh[j + 3] = t.w;
+            for (int k = 0; k < HN; ++k) vh[k] = *(const uint4*)((const float*)hv + e + 4 * k);
+        } else {
+            vh[0] = *(const uint4*)((const T*)hv + e);
+        }
+    };
+    auto process = [&](size_t e, const uint4& vx, const uint4 (&vh)[HN]) __attribute__((always_inline)) {
+        float fx[EPB], fh[EPB];
+        Piece<T>::unpack(vx, fx);
+        if constexpr (HF32) {
+#pragma unroll
+            for (int k = 0; k < HN; ++k) {
+                fh[4 * k] = __uint_as_float(vh[k].x); fh[4 * k + 1] = __uint_as_float(vh[k].y);
+                fh[4 * k + 2] = __uint_as_float(vh[k].z); fh[4 * k + 3] = __uint_as_float(vh[k].w);
             }
         } else {
-            Piece<T>::unpack(*(const uint4*)((const T*)hv + e), fh);
+            Piece<T>::unpack(vh[0], fh);
         }
 #pragma unroll
         for (int j = 0; j < EPB; ++j) fx[j] = fx[j] + fmaf(HSILU ? silu_f(fh[j]) : fh[j], sc[j], sh[j]);
@@ -432,6 +483,42 @@ __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __re
         Piece<T>::unpack(pv, fx);
 #pragma unroll
         for (int j = 0; j < EPB; ++j) { s[j] += fx[j]; q[j] = fmaf(fx[j], fx[j], q[j]); }
+    };
+    if (!HF32) {
+        if (gn.stats) {  // uniform: finish the GroupNorm of h here (gn_fused.h)
+            float gam[EPB], bet[EPB];
+            GnInLoads ld;
+            gn_in_issue(gn, b, tid, bd, ld);
+            gn_in_params<EPB>(gn, c * EPB, gam, bet);
+            gn_in_reduce(gn, b, tid, bd, ld, scr);
+            __syncthreads();
+            gn_in_fold<EPB>(gn, scr, bd >> 6, C, c * EPB, gam, bet, sc, sh);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) {
+                sc[j] = scale[(size_t)b * C + c * EPB + j];
+                sh[j] = shift[(size_t)b * C + c * EPB + j];
+            }
+        }
+    }
+    // four iterations' loads are issued together (unconditionally: out-of-range slots re-read piece 0 and are dropped; a load
+    // under a branch is waited for at once, and the loop used to be one load round trip + one store acknowledgement per
+    // iteration), then the four are processed and stored.  x may alias y: a thread only ever touches its own pieces.
+    const long long pc0 = (long long)part * iters * bd + tid;
+    for (int it0 = 0; it0 < iters; it0 += 4) {
+        uint4 vx[4], vh[4][HN];
+        size_t e[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long pc = pc0 + (long long)(it0 + u) * bd;
+            ok[u] = it0 + u < iters && pc < pieces;
+            e[u] = sbase + (size_t)(ok[u] ? pc : 0) * EPB;
+            load(e[u], vx[u], vh[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) process(e[u], vx[u], vh[u]);
     }
     if (stats) {
         const int R = bd / CPP, row = tid / CPP;
@@ -441,30 +528,41 @@ __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __re
             red[(row * C + c * EPB + j) * 2 + 1] = q[j];
         }
         __syncthreads();
+        float* const chan = red + R * C * 2;  // the workgroup's per-channel totals (group format)
         for (int i = tid; i < C * 2; i += bd) {
             float t = 0.f;
+#pragma unroll 8
             for (int r = 0; r < R; ++r) t += red[r * C * 2 + i];
-            stats[(((size_t)b * gridDim.x + part) * C) * 2 + i] = t;
+            if (groups) chan[i] = t;
+            else stats[(((size_t)b * gridDim.x + part) * C) * 2 + i] = t;
+        }
+        if (groups) {  // group-format partials (gn_fused.h)
+            __syncthreads();
+            if (tid < 64) gn_bins_store<1>(chan, 0, C, 0, C, stats + ((size_t)b * gridDim.x + part) * kGnSlab, tid);
         }
     }
 }
 
 hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, const float* scale, const float* shift,
-                        void* y, float* stats, int B, int HW, int C, hipStream_t s) {
+                        void* y, float* stats, int B, int HW, int C, hipStream_t s, const GnIn* gn, int groups) {
     const int epb = dtype == DT_BF16 ? 8 : 4;
-    if (C % epb) return hipErrorInvalidValue;
+    if (C % epb || C % kGroups) return hipErrorInvalidValue;
     const int cpp = C / epb, bd = resid_bd(cpp);
     if (bd % cpp) return hipErrorInvalidValue;
+    GnIn g = {};
+    if (gn) g = *gn;
+    if (g.stats && (h_f32 == 1 || g.np > kGnFuseMaxParts)) return hipErrorInvalidValue;
     dim3 grid(resid_nparts(dtype, HW, C), B);
-    const size_t lds = stats ? (size_t)(bd / cpp) * C * 2 * 4 : 0;
+    const int iters = resid_iters(dtype, HW, C);
+    const size_t lds = (size_t)(bd / cpp) * C * 2 * 4 + (size_t)C * 2 * 4 + 4 * kGroups * 2 * 4;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
 #define DDIMX_RESID(TT, HF)                                                                                     \
-    hipLaunchKernelGGL((resid_kernel<TT, HF>), grid, dim3(bd), lds, s, (const TT*)x, h, scale, shift, (TT*)y, stats, HW, C)
+    hipLaunchKernelGGL((resid_kernel<TT, HF>), grid, dim3(bd), lds, s, (const TT*)x, h, scale, shift, (TT*)y, stats, HW, C, g, groups, iters)
     if (h_f32 == 2) {  // training forward: h holds the pre-activation, y = x + SiLU(h)*scale + shift
         if (dtype == DT_BF16)
-            hipLaunchKernelGGL((resid_kernel<__bf16, false, true>), grid, dim3(bd), lds, s, (const __bf16*)x, h, scale, shift, (__bf16*)y, stats, HW, C);
+            hipLaunchKernelGGL((resid_kernel<__bf16, false, true>), grid, dim3(bd), lds, s, (const __bf16*)x, h, scale, shift, (__bf16*)y, stats, HW, C, g, groups, iters);
         else
-            hipLaunchKernelGGL((resid_kernel<float, false, true>), grid, dim3(bd), lds, s, (const float*)x, h, scale, shift, (float*)y, stats, HW, C);
+            hipLaunchKernelGGL((resid_kernel<float, false, true>), grid, dim3(bd), lds, s, (const float*)x, h, scale, shift, (float*)y, stats, HW, C, g, groups, iters);
     } else if (dtype == DT_BF16) { if (h_f32) DDIMX_RESID(__bf16, true); else DDIMX_RESID(__bf16, false); }
     else { if (h_f32) DDIMX_RESID(float, true); else DDIMX_RESID(float, false); }
 #undef DDIMX_RESID
@@ -475,7 +573,7 @@ hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, cons
 // ---- per-channel statistics of an NHWC tensor (used when a tensor arrives without producer stats) ----
 template <typename T>
 __global__ void __launch_bounds__(256) tensor_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int HW,
-                                                           int C) {
+                                                           int C, int groups, int iters) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -484,8 +582,8 @@ __global__ void __launch_bounds__(256) tensor_stats_kernel(const T* __restrict__
     float s[EPB], q[EPB];
 #pragma unroll
     for (int j = 0; j < EPB; ++j) s[j] = q[j] = 0.f;
-    for (int it = 0; it < kResidIters; ++it) {
-        const long long pc = ((long long)part * kResidIters + it) * bd + tid;
+    for (int it = 0; it < iters; ++it) {
+        const long long pc = ((long long)part * iters + it) * bd + tid;
         if (pc >= pieces) break;
         float f[EPB];
         Piece<T>::unpack(*(const uint4*)(x + (size_t)b * HW * C + (size_t)pc * EPB), f);
@@ -499,21 +597,28 @@ __global__ void __launch_bounds__(256) tensor_stats_kernel(const T* __restrict__
         red[(row * C + c * EPB + j) * 2 + 1] = q[j];
     }
     __syncthreads();
+    float* const chan = red + R * C * 2;
     for (int i = tid; i < C * 2; i += bd) {
         float t = 0.f;
+#pragma unroll 8
         for (int r = 0; r < R; ++r) t += red[r * C * 2 + i];
-        stats[(((size_t)b * gridDim.x + part) * C) * 2 + i] = t;
+        if (groups) chan[i] = t;
+        else stats[(((size_t)b * gridDim.x + part) * C) * 2 + i] = t;
+    }
+    if (groups) {
+        __syncthreads();
+        if (tid < 64) gn_bins_store<1>(chan, 0, C, 0, C, stats + ((size_t)b * gridDim.x + part) * kGnSlab, tid);
     }
 }
-hipError_t tensor_stats_launch(int dtype, const void* x, float* stats, int B, int HW, int C, hipStream_t s) {
+hipError_t tensor_stats_launch(int dtype, const void* x, float* stats, int B, int HW, int C, hipStream_t s, int groups) {
     const int epb = dtype == DT_BF16 ? 8 : 4;
-    if (C % epb) return hipErrorInvalidValue;
+    if (C % epb || (groups && C % kGroups)) return hipErrorInvalidValue;
     const int cpp = C / epb, bd = resid_bd(cpp);
     if (bd % cpp) return hipErrorInvalidValue;
     dim3 grid(resid_nparts(dtype, HW, C), B);
-    const size_t lds = (size_t)(bd / cpp) * C * 2 * 4;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(tensor_stats_kernel<__bf16>, grid, dim3(bd), lds, s, (const __bf16*)x, stats, HW, C);
-    else hipLaunchKernelGGL(tensor_stats_kernel<float>, grid, dim3(bd), lds, s, (const float*)x, stats, HW, C);
+    const size_t lds = (size_t)(bd / cpp) * C * 2 * 4 + (size_t)C * 2 * 4;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(tensor_stats_kernel<__bf16>, grid, dim3(bd), lds, s, (const __bf16*)x, stats, HW, C, groups, resid_iters(dtype, HW, C));
+    else hipLaunchKernelGGL(tensor_stats_kernel<float>, grid, dim3(bd), lds, s, (const float*)x, stats, HW, C, groups, resid_iters(dtype, HW, C));
     return hipGetLastError();
 }
 

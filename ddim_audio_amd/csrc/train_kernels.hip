@@ -70,14 +70,13 @@ __device__ __forceinline__ float dsilu_f(float u) { const float s = sigmoid_f(u)
 //   MODE 1 (GroupNorm followed by SiLU: GN0):      g' = g * SiLU'(scale*x + shift), v = x      (u = x)
 // same partitioning as tensor_stats / resid (resid_nparts), output [B][nparts][C][2]
 // =====================================================================================================
-constexpr int kTrIters = 16;
 static inline int tr_bd(int cpp) { return (cpp % 3 == 0) ? 192 : 256; }
 static inline int tr_nparts(int dtype, int HW, int C) { return resid_nparts(dtype, HW, C); }
 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__ g, const T* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           float* __restrict__ stats, int HW, int C) {
+                                                           float* __restrict__ stats, int HW, int C, int iters) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -90,8 +89,8 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
         sc[j] = MODE == 1 ? scale[(size_t)b * C + c * EPB + j] : 1.f;
         sh[j] = MODE == 1 ? shift[(size_t)b * C + c * EPB + j] : 0.f;
     }
-    for (int it = 0; it < kTrIters; ++it) {
-        const long long pc = ((long long)part * kTrIters + it) * bd + tid;
+    for (int it = 0; it < iters; ++it) {
+        const long long pc = ((long long)part * iters + it) * bd + tid;
         if (pc >= pieces) break;
         const size_t e = (size_t)b * HW * C + (size_t)pc * EPB;
         float fg[EPB], fu[EPB];
@@ -127,7 +126,7 @@ hipError_t gn_bwd_stats_launch(int dtype, int mode, const void* g, const void* u
     if (bd % cpp) return hipErrorInvalidValue;
     dim3 grid(tr_nparts(dtype, HW, C), B);
     const size_t lds = (size_t)(bd / cpp) * C * 2 * 4;
-#define DDIMX_L(TT, M) hipLaunchKernelGGL((gn_bwd_stats_kernel<TT, M>), grid, dim3(bd), lds, s, (const TT*)g, (const TT*)u, scale, shift, stats, HW, C)
+#define DDIMX_L(TT, M) hipLaunchKernelGGL((gn_bwd_stats_kernel<TT, M>), grid, dim3(bd), lds, s, (const TT*)g, (const TT*)u, scale, shift, stats, HW, C, resid_iters(dtype, HW, C))
     if (dtype == DT_BF16) { if (mode) DDIMX_L(__bf16, 1); else DDIMX_L(__bf16, 0); }
     else { if (mode) DDIMX_L(float, 1); else DDIMX_L(float, 0); }
 #undef DDIMX_L
@@ -282,7 +281,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ gy, const T* __restrict__ extra,
                                                            const float* __restrict__ coef, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ out,
-                                                           float* __restrict__ sums, int HW, int C) {
+                                                           float* __restrict__ sums, int HW, int C, int iters) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -299,8 +298,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         sh[j] = MODE == 1 ? shift[(size_t)b * C + ch] : 0.f;
         acc[j] = 0.f;
     }
-    for (int it = 0; it < kTrIters; ++it) {
-        const long long pc = ((long long)part * kTrIters + it) * bd + tid;
+    for (int it = 0; it < iters; ++it) {
+        const long long pc = ((long long)part * iters + it) * bd + tid;
         if (pc >= pieces) break;
         const size_t e = (size_t)b * HW * C + (size_t)pc * EPB;
         float fg[EPB], fu[EPB], fo[EPB];
@@ -359,7 +358,7 @@ hipError_t gn_bwd_apply_launch(int dtype, int mode, const void* g, const void* u
     const size_t lds = (size_t)(bd / cpp) * C * 4;
 #define DDIMX_L(TT, M)                                                                                                      \
     hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, M>), grid, dim3(bd), lds, s, (const TT*)g, (const TT*)u, (const TT*)gy, \
-                       (const TT*)extra, coef, scale, shift, (TT*)out, sums, HW, C)
+                       (const TT*)extra, coef, scale, shift, (TT*)out, sums, HW, C, resid_iters(dtype, HW, C))
     if (dtype == DT_BF16) { if (mode) DDIMX_L(__bf16, 1); else DDIMX_L(__bf16, 0); }
     else { if (mode) DDIMX_L(float, 1); else DDIMX_L(float, 0); }
 #undef DDIMX_L

@@ -27,6 +27,6 @@ for f in files:
                 if mm:
                     n = f"conv<{'bf16' if mm.group(1) == 'DF16b' else 'f32'},cin={mm.group(2)},nout={mm.group(3)},nb={mm.group(4)},mode={mm.group(5)},tile={mm.group(6)}x{mm.group(7)},waves={mm.group(8)}x{mm.group(9)}>"
                 flag = "  <-- SPILL/SCRATCH" if cur.get("Spill", "0") != "0" or cur.get("ScratchSize", "0") != "0" else ""
-                print(f"{f:24s} V={cur.get('VGPRs'):>4} A={cur.get('AGPRs'):>4} occ={cur.get('Occupancy')} spill={cur.get('Spill')} "
+                print(f"{f:24s} LDS={cur.get('LDS')} V={cur.get('VGPRs'):>4} A={cur.get('AGPRs'):>4} occ={cur.get('Occupancy')} spill={cur.get('Spill')} "
                       f"scratch={cur.get('ScratchSize')}  {n[:90]}{flag}")
                 cur = None
