@@ -424,6 +424,10 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         if (tiles_s / 4 > wps) wps = tiles_s / 4;  // long spectrograms (T >= 2048): at most 4 tiles per workgroup, so that a
                                                    // single sample still fills the 256 CUs
         if (q.cin >= 64 && tiles_s >= 512 && wps < 256) wps = 256;  // streamed-weight levels of long samples: 2 tiles per workgroup
+        // Down / Upsample with exactly one tile per workgroup (levels 1-2 at T = 1024): two tiles per workgroup halve the
+        // per-workgroup costs (82 KB of weights, statistics tail): 114 -> 106 / 97 -> 88 / 61 -> 58 us at B = 8
+        // (profiles/r02/downup_wps.txt); a single short sample pays about 12 us per launch for the emptier grid.
+        if (q.mode != CONV3 && tiles_s == 128) wps = 64;
         // A/B hook (off): two tiles per workgroup at level 2 (one workgroup per CU, 64-128 tiles per sample).  Alone the launch
         // gains 9 % at B = 8 (44.1 -> 40.3 us, profiles/r02/conv_wps_deep_levels.txt), but inside the step the two batch shards
         // run B = 4 launches, for which it halves an already half-empty grid: 1 803 vs 1 814 sample-fwd/s.

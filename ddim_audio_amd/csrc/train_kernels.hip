@@ -89,20 +89,35 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
         sc[j] = MODE == 1 ? scale[(size_t)b * C + c * EPB + j] : 1.f;
         sh[j] = MODE == 1 ? shift[(size_t)b * C + c * EPB + j] : 0.f;
     }
-    for (int it = 0; it < iters; ++it) {
-        const long long pc = ((long long)part * iters + it) * bd + tid;
-        if (pc >= pieces) break;
-        const size_t e = (size_t)b * HW * C + (size_t)pc * EPB;
-        float fg[EPB], fu[EPB];
-        Piece<T>::unpack(*(const uint4*)(g + e), fg);
-        Piece<T>::unpack(*(const uint4*)(u + e), fu);
+    // four iterations' loads are issued together, unconditionally (out-of-range slots re-read piece 0 and are dropped): one
+    // load round trip per four iterations instead of one per iteration
+    const long long pc0 = (long long)part * iters * bd + tid;
+    const size_t sbase = (size_t)b * HW * C;
+    for (int it0 = 0; it0 < iters; it0 += 4) {
+        uint4 vg[4], vu[4];
+        bool ok[4];
 #pragma unroll
-        for (int j = 0; j < EPB; ++j) {
-            float gp, v;
-            if (MODE == 0) { gp = fg[j]; v = silu_f(fu[j]); }
-            else { gp = fg[j] * dsilu_f(fmaf(fu[j], sc[j], sh[j])); v = fu[j]; }
-            P[j] += gp;
-            Q[j] = fmaf(gp, v, Q[j]);
+        for (int k = 0; k < 4; ++k) {
+            const long long pc = pc0 + (long long)(it0 + k) * bd;
+            ok[k] = it0 + k < iters && pc < pieces;
+            const size_t e = sbase + (size_t)(ok[k] ? pc : 0) * EPB;
+            vg[k] = *(const uint4*)(g + e);
+            vu[k] = *(const uint4*)(u + e);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            float fg[EPB], fu[EPB];
+            Piece<T>::unpack(vg[k], fg);
+            Piece<T>::unpack(vu[k], fu);
+#pragma unroll
+            for (int j = 0; j < EPB; ++j) {
+                float gp, v;
+                if (MODE == 0) { gp = fg[j]; v = silu_f(fu[j]); }
+                else { gp = fg[j] * dsilu_f(fmaf(fu[j], sc[j], sh[j])); v = fu[j]; }
+                P[j] += gp;
+                Q[j] = fmaf(gp, v, Q[j]);
+            }
         }
     }
     const int R = bd / CPP, row = tid / CPP;
@@ -298,41 +313,59 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         sh[j] = MODE == 1 ? shift[(size_t)b * C + ch] : 0.f;
         acc[j] = 0.f;
     }
-    for (int it = 0; it < iters; ++it) {
-        const long long pc = ((long long)part * iters + it) * bd + tid;
-        if (pc >= pieces) break;
-        const size_t e = (size_t)b * HW * C + (size_t)pc * EPB;
-        float fg[EPB], fu[EPB], fo[EPB];
-        Piece<T>::unpack(*(const uint4*)(g + e), fg);
-        Piece<T>::unpack(*(const uint4*)(u + e), fu);
-        if (MODE == 0) {
+    // NIT iterations' loads are issued together, unconditionally (out-of-range slots re-read piece 0 and are dropped; an
+    // absent `extra` reads g in its place): one load round trip per NIT iterations instead of one per iteration
+    constexpr int NIT = MODE == 0 ? 4 : 2;
+    const long long pc0 = (long long)part * iters * bd + tid;
+    const size_t sbase = (size_t)b * HW * C;
+    const T* const pex = (MODE == 1 && extra) ? extra : g;
+    for (int it0 = 0; it0 < iters; it0 += NIT) {
+        uint4 vg[NIT], vu[NIT], vy[MODE == 1 ? NIT : 1], ve[MODE == 1 ? NIT : 1];
+        size_t e[NIT];
+        bool ok[NIT];
 #pragma unroll
-            for (int j = 0; j < EPB; ++j) {
-                const float sg = sigmoid_f(fu[j]);
-                const float ds = fmaf(ca[j], fg[j], fmaf(cb[j], fu[j] * sg, cc[j]));
-                fo[j] = ds * (sg * fmaf(fu[j], 1.0f - sg, 1.0f));
-            }
-        } else {
-            float fy[EPB];
-            Piece<T>::unpack(*(const uint4*)(gy + e), fy);
-#pragma unroll
-            for (int j = 0; j < EPB; ++j) {
-                const float gp = fg[j] * dsilu_f(fmaf(fu[j], sc[j], sh[j]));
-                fo[j] = fy[j] + fmaf(ca[j], gp, fmaf(cb[j], fu[j], cc[j]));
-            }
-            if (extra) {
-                float fe[EPB];
-                Piece<T>::unpack(*(const uint4*)(extra + e), fe);
-#pragma unroll
-                for (int j = 0; j < EPB; ++j) fo[j] += fe[j];
+        for (int k = 0; k < NIT; ++k) {
+            const long long pc = pc0 + (long long)(it0 + k) * bd;
+            ok[k] = it0 + k < iters && pc < pieces;
+            e[k] = sbase + (size_t)(ok[k] ? pc : 0) * EPB;
+            vg[k] = *(const uint4*)(g + e[k]);
+            vu[k] = *(const uint4*)(u + e[k]);
+            if (MODE == 1) {
+                vy[k] = *(const uint4*)(gy + e[k]);
+                ve[k] = *(const uint4*)(pex + e[k]);
             }
         }
-        const uint4 pv = Piece<T>::pack(fo);
-        *(uint4*)(out + e) = pv;
-        if (MODE == 0) {
-            Piece<T>::unpack(pv, fo);  // sums of the values as stored (what the weight-gradient kernel will read)
 #pragma unroll
-            for (int j = 0; j < EPB; ++j) acc[j] += fo[j];
+        for (int k = 0; k < NIT; ++k) {
+            if (!ok[k]) continue;
+            float fg[EPB], fu[EPB], fo[EPB];
+            Piece<T>::unpack(vg[k], fg);
+            Piece<T>::unpack(vu[k], fu);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < EPB; ++j) {
+                    const float sg = sigmoid_f(fu[j]);
+                    const float ds = fmaf(ca[j], fg[j], fmaf(cb[j], fu[j] * sg, cc[j]));
+                    fo[j] = ds * (sg * fmaf(fu[j], 1.0f - sg, 1.0f));
+                }
+            } else {
+                float fy[EPB], fe[EPB];
+                Piece<T>::unpack(vy[k], fy);
+                Piece<T>::unpack(ve[k], fe);
+#pragma unroll
+                for (int j = 0; j < EPB; ++j) {
+                    const float gp = fg[j] * dsilu_f(fmaf(fu[j], sc[j], sh[j]));
+                    fo[j] = fy[j] + fmaf(ca[j], gp, fmaf(cb[j], fu[j], cc[j]));
+                    if (extra) fo[j] += fe[j];
+                }
+            }
+            const uint4 pv = Piece<T>::pack(fo);
+            *(uint4*)(out + e[k]) = pv;
+            if (MODE == 0) {
+                Piece<T>::unpack(pv, fo);  // sums of the values as stored (what the weight-gradient kernel will read)
+#pragma unroll
+                for (int j = 0; j < EPB; ++j) acc[j] += fo[j];
+            }
         }
     }
     if (MODE == 0 && sums) {
