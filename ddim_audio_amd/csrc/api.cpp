@@ -390,13 +390,56 @@ struct BatchPlanScope {
     BatchPlanScope() { g_batch_plan = true; }
     ~BatchPlanScope() { g_batch_plan = false; }
 };
+// Plan of one conv launch: tile configuration and the persistent-workgroup split.
+struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; };
+static int conv_plan(const ConvCall& q, ConvPlan* p) {
+    ConvGeom& g = p->g;
+    if (q.mode == DOWN4 && ((q.Hin | q.Win) & 1)) return fail("downsample needs even H, W (got %d x %d)", q.Hin, q.Win);
+    p->Hv = q.mode == DOWN4 ? q.Hin / 2 : q.Hin;
+    p->Wv = q.mode == DOWN4 ? q.Win / 2 : q.Win;
+    p->var = conv_pick_variant(q.dtype, q.mode, q.cin, q.cout, (q.batch_plan || g_batch_plan) ? q.B : 0, p->Hv, p->Wv);
+    if (conv_geometry(q.dtype, q.mode, q.cin, q.cout, p->var, &g) != hipSuccess)
+        return fail("conv %d->%d mode %d dtype %d: no kernel", q.cin, q.cout, q.mode, q.dtype);
+    p->tiles_x = cdiv(p->Wv, g.tw);
+    p->tiles_y = cdiv(p->Hv, g.th);
+    // persistent workgroups: each walks tiles_per_wg consecutive tiles of ONE sample.  The split depends only
+    // on the sample's size, never on the batch, so a sample's statistics partials (and hence its result, bit
+    // for bit) are the same alone, inside any batch, or on any number of GPUs.
+    const int tiles_s = p->tiles_x * p->tiles_y;
+    int wps = tiles_s < 128 ? tiles_s : 128;
+    if (tiles_s / 4 > wps) wps = tiles_s / 4;  // long spectrograms (T >= 2048): at most 4 tiles per workgroup, so that a
+                                               // single sample still fills the 256 CUs
+    if (q.cin >= 64 && tiles_s >= 512 && wps < 256) wps = 256;  // streamed-weight levels of long samples: 2 tiles per workgroup
+    // Down / Upsample with exactly one tile per workgroup (levels 1-2 at T = 1024): two tiles per workgroup halve the
+    // per-workgroup costs (82 KB of weights, statistics tail): 114 -> 106 / 97 -> 88 / 61 -> 58 us at B = 8
+    // (profiles/r02/downup_wps.txt); a single short sample pays about 12 us per launch for the emptier grid.
+    if (q.mode != CONV3 && tiles_s == 128) wps = 64;
+    // A/B hook (off): two tiles per workgroup at level 2 (one workgroup per CU, 64-128 tiles per sample).  Alone the launch
+    // gains 9 % at B = 8 (44.1 -> 40.3 us, profiles/r02/conv_wps_deep_levels.txt), but inside the step the two batch shards
+    // run B = 4 launches, for which it halves an already half-empty grid: 1 803 vs 1 814 sample-fwd/s.
+    if (knobs().two_tiles && g.nb == g.nout && g.lds_bytes > 80 * 1024 && tiles_s >= 64 && tiles_s <= 128 && q.mode == CONV3) wps = tiles_s / 2;
+    if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
+    p->tiles_per_wg = cdiv(tiles_s, wps);
+    p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
+    return 0;
+}
+constexpr int kNumCUs = 256;  // MI355X
+// consumer-side GroupNorm finalisation pays 1-1.5 us per round of workgroups (prologue + the producer's tail), a finalize launch
+// 5 us + a kernel boundary that the other batch shard partly fills: B = 8 stays launch-free, B >= 32 mostly does not
+constexpr int kGnFuseConvRounds = 3, kGnFuseResidRounds = 2;
+// how many times over the launch fills the chip (workgroup "rounds" per CU slot)
+static int conv_rounds(const ConvPlan& p, int B) {
+    const long long wgs = (long long)p.wgs_per_sample * B * (p.g.nout / p.g.nb) * p.g.classes;
+    int per_cu = (160 * 1024) / p.g.lds_bytes;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2048 / p.g.nthreads) per_cu = 2048 / p.g.nthreads;
+    return (int)((wgs + (long long)kNumCUs * per_cu - 1) / ((long long)kNumCUs * per_cu));
+}
 // launches one fused conv; returns the stats slab geometry (nparts, Cs) it produced
 static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
-    ConvGeom g;
-    const int hv = q.mode == DOWN4 ? q.Hin / 2 : q.Hin, wv = q.mode == DOWN4 ? q.Win / 2 : q.Win;
-    const int var = conv_pick_variant(q.dtype, q.mode, q.cin, q.cout, (q.batch_plan || g_batch_plan) ? q.B : 0, hv, wv);
-    if (conv_geometry(q.dtype, q.mode, q.cin, q.cout, var, &g) != hipSuccess)
-        return fail("conv %d->%d mode %d dtype %d: no kernel", q.cin, q.cout, q.mode, q.dtype);
+    ConvPlan pl;
+    CHK(conv_plan(q, &pl));
+    const ConvGeom& g = pl.g;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = q.in; a.w = q.w; a.bias = q.bias; a.chan_add = q.chan_add; a.chan_add_stride = q.chan_add_stride;
@@ -408,34 +451,10 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     if (q.groups && q.cout % kGroups) return fail("conv: group-format statistics need cout %% 8 == 0");
     a.B = q.B; a.Hin = q.Hin; a.Win = q.Win;
     a.stamps = q.stamps;
-    if (q.mode == DOWN4) {
-        if ((q.Hin | q.Win) & 1) return fail("downsample needs even H, W (got %d x %d)", q.Hin, q.Win);
-        a.Hv = q.Hin / 2; a.Wv = q.Win / 2;
-    } else {
-        a.Hv = q.Hin; a.Wv = q.Win;
-    }
-    a.tiles_x = cdiv(a.Wv, g.tw);
-    a.tiles_y = cdiv(a.Hv, g.th);
-    {   // persistent workgroups: each walks tiles_per_wg consecutive tiles of ONE sample.  The split depends only
-        // on the sample's size, never on the batch, so a sample's statistics partials (and hence its result, bit
-        // for bit) are the same alone, inside any batch, or on any number of GPUs.
-        const int tiles_s = a.tiles_x * a.tiles_y;
-        int wps = tiles_s < 128 ? tiles_s : 128;
-        if (tiles_s / 4 > wps) wps = tiles_s / 4;  // long spectrograms (T >= 2048): at most 4 tiles per workgroup, so that a
-                                                   // single sample still fills the 256 CUs
-        if (q.cin >= 64 && tiles_s >= 512 && wps < 256) wps = 256;  // streamed-weight levels of long samples: 2 tiles per workgroup
-        // Down / Upsample with exactly one tile per workgroup (levels 1-2 at T = 1024): two tiles per workgroup halve the
-        // per-workgroup costs (82 KB of weights, statistics tail): 114 -> 106 / 97 -> 88 / 61 -> 58 us at B = 8
-        // (profiles/r02/downup_wps.txt); a single short sample pays about 12 us per launch for the emptier grid.
-        if (q.mode != CONV3 && tiles_s == 128) wps = 64;
-        // A/B hook (off): two tiles per workgroup at level 2 (one workgroup per CU, 64-128 tiles per sample).  Alone the launch
-        // gains 9 % at B = 8 (44.1 -> 40.3 us, profiles/r02/conv_wps_deep_levels.txt), but inside the step the two batch shards
-        // run B = 4 launches, for which it halves an already half-empty grid: 1 803 vs 1 814 sample-fwd/s.
-        if (knobs().two_tiles && g.nb == g.nout && g.lds_bytes > 80 * 1024 && tiles_s >= 64 && tiles_s <= 128 && q.mode == CONV3) wps = tiles_s / 2;
-        if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
-        a.tiles_per_wg = cdiv(tiles_s, wps);
-        a.wgs_per_sample = cdiv(tiles_s, a.tiles_per_wg);
-    }
+    a.Hv = pl.Hv; a.Wv = pl.Wv;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
+    a.tiles_per_wg = pl.tiles_per_wg; a.wgs_per_sample = pl.wgs_per_sample;
+    const int var = pl.var;
     if (nparts) *nparts = a.wgs_per_sample * g.classes * (q.groups ? g.nout / g.nb : 1);
     if (Cs) *Cs = g.nout;
     HIPCHK(conv_launch(q.dtype, q.mode, q.cin, q.cout, var, a, s));
@@ -476,27 +495,36 @@ static int run_resblock(int dtype, int C, const void* x, void* y, const float* t
     int np = 0, cs = 0;
     if (stats2) {
         if (tape) return fail("run_resblock: the launch-free GroupNorm path keeps no tape");
-        // GroupNorm input of one consumer: in-kernel when the partials are few, else scale / shift from one launch
-        auto gn_of = [&](const float* st, int n, const float* gamma, const float* beta, GnIn* g, bool* fused, int which) -> int {
+        // GroupNorm input of one consumer: finished inside the consumer, or -- scale / shift from one launch -- when the sample
+        // has too many partials, or when the consumer launch fills the chip so many times over that its per-workgroup prologue
+        // (about a microsecond per round) costs more than the launch it saves (large batches).  Either way the numbers are the
+        // same bit for bit: gn_finalize_groups runs the consumer's own reduction with the consumer's block size.
+        auto gn_of = [&](const float* st, int n, const float* gamma, const float* beta, GnIn* g, bool* fused, int which, int rounds,
+                         int max_rounds, int nthreads) -> int {
             *g = GnIn{st, gamma, beta, 1.0 / cnt, eps, n};
-            *fused = n <= kGnFuseMaxParts;
-            if (!*fused || (knobs().gn_dbg & which)) HIPCHK(gn_finalize_groups_launch(*g, C, scale, shift, B, s));
+            *fused = n <= kGnFuseMaxParts && rounds <= max_rounds && !(knobs().gn_dbg & which);
+            if (!*fused) HIPCHK(gn_finalize_groups_launch(*g, C, scale, shift, B, nthreads, s));
             return 0;
         };
         GnIn g; bool fu;
-        CHK(gn_of(stats, x_nparts, p.g0, p.b0, &g, &fu, 2));
         ConvCall k1 = {dtype, CONV3, C, C, x, p.w0, nullptr, temb, temb_stride, scale, shift, XF_AFFINE_SILU, 1, nullptr, h1, stats2, B, H, W};
-        if (fu && !(knobs().gn_dbg & 2)) k1.gn = g;
+        ConvPlan pl;
+        CHK(conv_plan(k1, &pl));
+        const int crounds = conv_rounds(pl, B);
+        CHK(gn_of(stats, x_nparts, p.g0, p.b0, &g, &fu, 2, crounds, kGnFuseConvRounds, pl.g.nthreads));
+        if (fu) k1.gn = g;
         k1.groups = true;
         CHK(run_conv(k1, s, &np, &cs));
-        CHK(gn_of(stats2, np, p.g1, p.b1, &g, &fu, 2));
+        CHK(gn_of(stats2, np, p.g1, p.b1, &g, &fu, 2, crounds, kGnFuseConvRounds, pl.g.nthreads));
         ConvCall k2 = {dtype, CONV3, C, C, h1, p.w1, p.bias1, nullptr, 0, scale, shift, XF_AFFINE, 1, nullptr, h2, stats, B, H, W};
-        if (fu && !(knobs().gn_dbg & 2)) k2.gn = g;
+        if (fu) k2.gn = g;
         k2.groups = true;
         CHK(run_conv(k2, s, &np, &cs));
-        CHK(gn_of(stats, np, p.g2, nullptr, &g, &fu, 1));
-        HIPCHK(resid_launch(dtype, x, h2, 0, scale, shift, y, want_stats ? stats2 : nullptr, B, H * W, C, s, (fu && !(knobs().gn_dbg & 1)) ? &g : nullptr, 1));
-        if (y_nparts) *y_nparts = resid_nparts(dtype, H * W, C);
+        const int rparts = resid_nparts(dtype, H * W, C);
+        const int rrounds = (int)(((long long)rparts * B + kNumCUs * 8 - 1) / (kNumCUs * 8));
+        CHK(gn_of(stats, np, p.g2, nullptr, &g, &fu, 1, rrounds, kGnFuseResidRounds, resid_threads(dtype, C)));
+        HIPCHK(resid_launch(dtype, x, h2, 0, scale, shift, y, want_stats ? stats2 : nullptr, B, H * W, C, s, fu ? &g : nullptr, 1));
+        if (y_nparts) *y_nparts = rparts;
         return 0;
     }
     float *sc0 = scale, *sh0 = shift, *sc1 = scale, *sh1 = shift, *sc2 = scale, *sh2 = shift;

@@ -129,7 +129,7 @@ __device__ __forceinline__ void gn_in_fold(const GnIn& gi, const float* scr, int
         const float m = hi ? m_hi : m_lo, r = hi ? r_hi : r_lo;
         const float s = r * gam[j];
         sc[j] = s;
-        sh[j] = bet[j] - m * s;
+        sh[j] = fmaf(-m, s, bet[j]);
     }
 }
 

@@ -22,7 +22,8 @@ hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, dou
                               const float* beta /*nullable*/, float eps, float* scale, float* shift, int B,
                               hipStream_t s, float* mean_rstd_out /*[B][8][2], nullable*/ = nullptr);
 // the same from group-format partials (gn.stats [B][gn.np][8][2])
-hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float* shift, int B, hipStream_t s);
+hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float* shift, int B, int nthreads, hipStream_t s);
+int resid_threads(int dtype, int C);  // block size of resid_kernel / tensor_stats for C channels
 
 // ---- residual pass: y = x + (h*scale + shift)  (block tail, models/diffusion.py:54-56), or y = x + h ----
 // h_f32 = 1: h is fp32 (FNet output) and no affine is applied; h_f32 = 2: y = x + SiLU(h)*scale + shift (training

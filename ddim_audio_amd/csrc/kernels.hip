@@ -388,25 +388,27 @@ hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, dou
 
 // The same from group-format partials (gn_fused.h) -- used where a sample has more than kGnFuseMaxParts partials (long
 // spectrograms at the shallow levels), so that consumers need not re-read them per workgroup.  One block per sample.
-__global__ void __launch_bounds__(256) gn_finalize_groups_kernel(const GnIn gn, int C, float* __restrict__ scale,
+__global__ void __launch_bounds__(512) gn_finalize_groups_kernel(const GnIn gn, int C, float* __restrict__ scale,
                                                                  float* __restrict__ shift) {
-    __shared__ float scr[4 * kGroups * 2];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float scr[8 * kGroups * 2];
+    const int b = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
     GnInLoads ld;
-    gn_in_issue(gn, b, tid, 256, ld);
-    gn_in_reduce(gn, b, tid, 256, ld, scr);
+    gn_in_issue(gn, b, tid, bd, ld);
+    gn_in_reduce(gn, b, tid, bd, ld, scr);
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += bd) {
         float m, r;
-        gn_in_group(gn, scr, 4, c / (C / kGroups), &m, &r);
+        gn_in_group(gn, scr, bd >> 6, c / (C / kGroups), &m, &r);
         const float sc = r * gn.gamma[c];
         scale[(size_t)b * C + c] = sc;
-        shift[(size_t)b * C + c] = (gn.beta ? gn.beta[c] : 0.f) - m * sc;
+        shift[(size_t)b * C + c] = fmaf(-m, sc, gn.beta ? gn.beta[c] : 0.f);
     }
 }
-hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float* shift, int B, hipStream_t s) {
-    if (C % kGroups) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(B), dim3(256), 0, s, gn, C, scale, shift);
+// nthreads: the block size of the consumer this replaces the in-kernel finalisation of (64 .. 512, a multiple of 64) -- the
+// reduction order, and with it every bit of the result, is a function of (gn.np, nthreads)
+hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float* shift, int B, int nthreads, hipStream_t s) {
+    if (C % kGroups || nthreads < 64 || nthreads > 512 || nthreads % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(B), dim3(nthreads), 0, s, gn, C, scale, shift);
     return hipGetLastError();
 }
 
@@ -415,6 +417,7 @@ hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float*
 // =====================================================================================================
 constexpr int kResidIters = 16;  // at most: 16-byte pieces per thread
 static inline int resid_bd(int cpp) { return (cpp % 3 == 0) ? 192 : 256; }
+int resid_threads(int dtype, int C) { return resid_bd(C / (dtype == DT_BF16 ? 8 : 4)); }
 // Pieces per thread of the element-wise passes over one sample (resid, tensor_stats, the GroupNorm-backward passes):
 // 16 where the sample is large, fewer on the deep levels so that a sample still spreads over >= 64 workgroups -- with 16
 // the level-5 tensor (8 192 pieces) was two workgroups per sample, each a chain of 16 dependent load round trips.
