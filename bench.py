@@ -189,7 +189,22 @@ def training_leg(args, cfg, dev, rank, world, backend, steps=3):
                 m.grad_sync(m._flat_grad)
             torch.cuda.synchronize()
             ar_ms = (time.perf_counter() - ta) / 3 * 1e3
-        res = {"value": world * b / dt, "grad_allreduce_ms": ar_ms, "grad_mb": (m._flat_grad.numel() * 4 / 1e6 if getattr(m, "_flat_grad", None) is not None else None), "unit": "train samples/s", "ms_per_step": dt * 1e3, "batch_per_gpu": b, "t_size": args.t_size,
+        graphed_ms = None
+        if world == 1:  # the same step replayed from one hipGraph (bit-identical to the eager step, tests/test_gpu_configs.py)
+            try:
+                gstep = train.GraphedTrainStep(m, state, alphas, warmup=1)
+                for _ in range(3):
+                    gstep(x)
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                for _ in range(steps):
+                    loss, _ = gstep(x)
+                torch.cuda.synchronize()
+                graphed_ms = (time.perf_counter() - tg) / steps * 1e3
+                gstep.close()
+            except Exception as ex:
+                graphed_ms = f"{type(ex).__name__}: {ex}"[:200]
+        res = {"value": world * b / dt, "graphed_ms_per_step": graphed_ms, "grad_allreduce_ms": ar_ms, "grad_mb": (m._flat_grad.numel() * 4 / 1e6 if getattr(m, "_flat_grad", None) is not None else None), "unit": "train samples/s", "ms_per_step": dt * 1e3, "batch_per_gpu": b, "t_size": args.t_size,
                "steps": steps, "optimizer": "fused AdamW (both groups), clip 1.0, EMA 0.9999", "loss_finite": bool(torch.isfinite(loss)),
                "model_tflops": world * b * 3 * 159.22e9 * args.t_size / 1024.0 / dt / 1e12,
                "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}

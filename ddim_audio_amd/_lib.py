@@ -32,6 +32,7 @@ _SIGS = {
     "ddimx_last_error": (c_char_p, []),
     "ddimx_create": (c_int, [POINTER(DdimxConfig), POINTER(c_void_p)]),
     "ddimx_destroy": (c_int, [c_void_p]),
+    "ddimx_set_dropout_counter": (c_int, [c_void_p, c_void_p]),
     "ddimx_num_params": (c_int, [c_void_p]),
     "ddimx_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_longlong)]),
     "ddimx_packed_bytes": (c_longlong, [c_void_p]),
@@ -106,6 +107,7 @@ _SIGS = {
     "ddimx_grad_norm_multi": (c_int, [c_void_p] * 4 + [c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ddimx_scale_multi": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),
     "ddimx_adam_multi": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
+    "ddimx_adam_multi_dyn": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -134,6 +134,7 @@ struct ddimx_ctx {
     struct FL { int ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b; };
     std::vector<FL> fl;
     std::vector<int> emb_off_down, emb_off_up;  // temb chunk offsets per block, execution order
+    const unsigned long long* dropout_ctr = nullptr;  // device counter added to every dropout seed (ddimx_set_dropout_counter)
 };
 
 static int add_spec(ddimx_ctx* c, const std::string& name, int kind, int d0, int d1 = 1, int d2 = 1, int d3 = 1) {
@@ -753,6 +754,11 @@ int ddimx_create(const ddimx_config* cfg, ddimx_handle* out) {
     return 0;
 }
 int ddimx_destroy(ddimx_handle h) { delete h; return 0; }
+int ddimx_set_dropout_counter(ddimx_handle h, const unsigned long long* counter) {
+    if (!h) return fail("ddimx_set_dropout_counter: null handle");
+    h->dropout_ctr = counter;
+    return 0;
+}
 int ddimx_num_params(ddimx_handle h) { return h ? (int)h->specs.size() : 0; }
 int ddimx_param_info(ddimx_handle h, int i, const char** name, long long* numel) {
     if (!h || i < 0 || i >= (int)h->specs.size()) return fail("ddimx_param_info: index %d out of range", i);
@@ -1307,21 +1313,21 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
     const float eps_ln = f.fnet_ln_eps;
     const int bf = c->fnet_bf16;
     HIPCHK(ln_train_launch(dt, cur, tables->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps_ln, tp.ln0, nullptr,
-                           tp.ln0_stat, M, width, 0.f, seed, 0, s));
+                           tp.ln0_stat, M, width, 0.f, seed, 0, s, c->dropout_ctr));
     CHK(tgemm(w, s, tp.ln0, pf(c, packed, c->proj_w), tp.X0, M, hid, width, pf(c, packed, c->proj_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
-    if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(tp.X0, tp.X0, (long long)M * hid, dropout_p, seed, 0, s));
+    if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(tp.X0, tp.X0, (long long)M * hid, dropout_p, seed, 0, s, c->dropout_ctr));
     const float* xc = tp.X0;
     for (int i = 0; i < f.fnet_layers; ++i) {
         const ddimx_ctx::FL& Lw = c->fl[i];
         const TrainTape::FLT& q = tp.fl[i];
         CHK(fourier_mix(c, tables, w, xc, q.Z, B, S, s));
         HIPCHK(ln_train_launch(DT_F32, q.Z, nullptr, 1, pf(c, packed, Lw.ln1_w), pf(c, packed, Lw.ln1_b), eps_ln, q.Y1, nullptr,
-                               q.zstat, M, hid, 0.f, seed, 0, s));
+                               q.zstat, M, hid, 0.f, seed, 0, s, c->dropout_ctr));
         CHK(tgemm(w, s, q.Y1, pf(c, packed, Lw.w1), q.pre, M, inter, hid, pf(c, packed, Lw.b1), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
         HIPCHK(gelu_launch(q.pre, nullptr, w.Hb, (long long)M * inter, 0, s));
         CHK(tgemm(w, s, w.Hb, pf(c, packed, Lw.w2), w.dXa, M, hid, inter, pf(c, packed, Lw.b2), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
         HIPCHK(ln_train_launch(DT_F32, w.dXa, q.Y1, M, pf(c, packed, Lw.ln2_w), pf(c, packed, Lw.ln2_b), eps_ln, q.Xout, q.s,
-                               q.sstat, M, hid, dropout_p, seed, (unsigned)(i + 1), s));
+                               q.sstat, M, hid, dropout_p, seed, (unsigned)(i + 1), s, c->dropout_ctr));
         xc = q.Xout;
     }
     CHK(tgemm(w, s, xc, pf(c, packed, c->cout_w), w.O, M, width, hid, pf(c, packed, c->cout_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
@@ -1490,7 +1496,7 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
                              M, hid, s));
         const float* dO2 = w.dXb;
         if (dropout_p > 0.f) {
-            HIPCHK(dropout_apply_launch(w.dXb, w.dZ, (long long)M * hid, dropout_p, seed, (unsigned)(i + 1), s));
+            HIPCHK(dropout_apply_launch(w.dXb, w.dZ, (long long)M * hid, dropout_p, seed, (unsigned)(i + 1), s, c->dropout_ctr));
             dO2 = w.dZ;
         }
         HIPCHK(colsum_launch(dO2, M, hid, hid, G(Lw.b2), s));
@@ -1510,7 +1516,7 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
         CHK(fourier_mix(c, tables, w, w.dXb, w.dXa, B, S, s));
     }
     {   // embedding: X0 = dropout(LN0(tok + posenc) Wp^T + bp)
-        if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(w.dXa, w.dXa, (long long)M * hid, dropout_p, seed, 0, s));
+        if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(w.dXa, w.dXa, (long long)M * hid, dropout_p, seed, 0, s, c->dropout_ctr));
         HIPCHK(colsum_launch(w.dXa, M, hid, hid, G(c->proj_b), s));
         HIPCHK(transpose_launch(w.dXa, w.T1, M, hid, 0, s));
         HIPCHK(transpose_launch(tp.ln0, w.T2, M, width, 0, s));
@@ -1910,6 +1916,20 @@ int ddimx_adam_multi(const long long* param_ptrs, const long long* grad_ptrs, co
     a.clip = clip; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.decoupled = decoupled;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.dyn = nullptr;
+    HIPCHK(adam_multi_launch(a, nblocks, (hipStream_t)stream));
+    return 0;
+}
+
+int ddimx_adam_multi_dyn(const long long* param_ptrs, const long long* grad_ptrs, const long long* m_ptrs, const long long* v_ptrs,
+                         const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks, const float* clip,
+                         const float* dyn, float beta1, float beta2, float eps, float weight_decay, int decoupled, void* stream) {
+    if (!dyn) return fail("ddimx_adam_multi_dyn: null dyn");
+    AdamArgs a;
+    a.p = param_ptrs; a.g = grad_ptrs; a.m = m_ptrs; a.v = v_ptrs; a.sizes = sizes; a.blk_tensor = blk_tensor; a.blk_off = blk_off;
+    a.clip = clip; a.lr = 0.f; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.decoupled = decoupled;
+    a.bc1 = 1.f; a.bc2s = 1.f;
+    a.dyn = dyn;
     HIPCHK(adam_multi_launch(a, nblocks, (hipStream_t)stream));
     return 0;
 }

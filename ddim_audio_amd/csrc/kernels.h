@@ -97,6 +97,7 @@ struct AdamArgs {
     const long long* p; const long long* g; const long long* m; const long long* v; const long long* sizes;
     const int* blk_tensor; const long long* blk_off; const float* clip;
     float lr, b1, b2, eps, wd, bc1, bc2s; int decoupled;
+    const float* dyn;  // nullable, device: {lr, bc1, bc2s} read when the kernel RUNS (graph-replayed steps) instead of the values above
 };
 hipError_t adam_multi_launch(const AdamArgs& a, int nblocks, hipStream_t s);
 hipError_t scale_multi_launch(const long long* ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,

@@ -995,13 +995,14 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamArgs a) {
     float* v = (float*)a.v[ti];
     const long long n = a.sizes[ti], off = a.blk_off[blockIdx.x];
     const float cc = a.clip ? a.clip[1] : 1.0f;
-    const float step_size = a.lr / a.bc1;
+    const float lr = a.dyn ? a.dyn[0] : a.lr, bc1 = a.dyn ? a.dyn[1] : a.bc1, bc2s = a.dyn ? a.dyn[2] : a.bc2s;
+    const float step_size = lr / bc1;
     for (int i = threadIdx.x; i < kEmaBlock; i += 256) {
         const long long k = off + i;
         if (k >= n) continue;
         float gk = __fmul_rn(g[k], cc);
         float pk = p[k];
-        if (a.decoupled) pk = __fmul_rn(pk, 1.0f - a.lr * a.wd);
+        if (a.decoupled) pk = __fmul_rn(pk, 1.0f - lr * a.wd);
         else gk = fmaf(a.wd, pk, gk);
         const float mk = fmaf(1.0f - a.b1, __fsub_rn(gk, m[k]), m[k]);
         float vk;
@@ -1011,7 +1012,7 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamArgs a) {
         } else {
             vk = fmaf(__fmul_rn(gk, gk), 1.0f - a.b2, __fmul_rn(v[k], a.b2));
         }
-        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vk), a.bc2s), a.eps);
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vk), bc2s), a.eps);
         pk = fmaf(-step_size, __fdiv_rn(mk, denom), pk);
         m[k] = mk; v[k] = vk; p[k] = pk;
     }

@@ -31,12 +31,13 @@ hipError_t pack_conv_dgrad_launch(int dtype, const float* w, void* dst, int O, i
 
 
 // ---- FNet bottleneck, training ---------------------------------------------------------------------------
+// seed_ctr (nullable, device memory): *seed_ctr is added to the seed when the kernel runs (graph-replayed training steps)
 hipError_t dropout_apply_launch(const float* src, float* dst, long long n, float p, unsigned long long seed, unsigned stream,
-                                hipStream_t s);
+                                hipStream_t s, const unsigned long long* seed_ctr = nullptr);
 // y = LN(drop(x) + add[m % add_rows]); sum_out (nullable) keeps the pre-norm rows, stat [M][2] = (mean, rstd)
 hipError_t ln_train_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma, const float* beta,
                            float eps, float* y, float* sum_out, float* stat, int M, int N, float p, unsigned long long seed,
-                           unsigned stream, hipStream_t s);
+                           unsigned stream, hipStream_t s, const unsigned long long* seed_ctr = nullptr);
 int ln_bwd_nblocks(int M);
 // partial: ln_bwd_nblocks(M) * 2 * N floats
 hipError_t ln_bwd_launch(int x_dtype, const float* dy, const void* x, const float* add, int add_rows, const float* stat,

@@ -434,16 +434,19 @@ __device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned 
 }
 static inline unsigned drop_thresh(float p) { return p <= 0.f ? 0u : (unsigned)((double)p * 4294967296.0); }
 
+// seed_ctr (nullable, device): added to the seed when the launch RUNS -- a training step replayed from a hipGraph keeps its
+// per-call mask stream by bumping that counter between replays, where an eager step passes a new seed by value
 __global__ void __launch_bounds__(256) dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n,
-                                                            unsigned long long seed, unsigned stream, unsigned thresh,
-                                                            float inv_keep) {
+                                                            unsigned long long seed, const unsigned long long* __restrict__ seed_ctr,
+                                                            unsigned stream, unsigned thresh, float inv_keep) {
+    if (seed_ctr) seed += *seed_ctr;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
         dst[i] = src[i] * dropout_keep(seed, stream, (unsigned long long)i, thresh, inv_keep);
 }
 hipError_t dropout_apply_launch(const float* src, float* dst, long long n, float p, unsigned long long seed, unsigned stream,
-                                hipStream_t s) {
+                                hipStream_t s, const unsigned long long* seed_ctr) {
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, seed, stream, drop_thresh(p),
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, seed, seed_ctr, stream, drop_thresh(p),
                        1.0f / (1.0f - p));
     return hipGetLastError();
 }
@@ -454,10 +457,12 @@ __global__ void __launch_bounds__(256) ln_train_kernel(const TX* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ y, float* __restrict__ sum_out,
                                                        float* __restrict__ stat, int N, unsigned long long seed,
-                                                       unsigned stream, unsigned thresh, float inv_keep) {
+                                                       const unsigned long long* __restrict__ seed_ctr, unsigned stream,
+                                                       unsigned thresh, float inv_keep) {
     __shared__ float red[4];
     __shared__ float bc;
     const int m = blockIdx.x, tid = threadIdx.x;
+    if (seed_ctr) seed += *seed_ctr;
     const TX* xr = x + (size_t)m * N;
     const float* ar = add ? add + (size_t)(m % add_rows) * N : nullptr;
     float v[8];
@@ -505,16 +510,16 @@ __global__ void __launch_bounds__(256) ln_train_kernel(const TX* __restrict__ x,
 }
 hipError_t ln_train_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma, const float* beta,
                            float eps, float* y, float* sum_out, float* stat, int M, int N, float p, unsigned long long seed,
-                           unsigned stream, hipStream_t s) {
+                           unsigned stream, hipStream_t s, const unsigned long long* seed_ctr) {
     if (N > 2048) return hipErrorInvalidValue;
     const unsigned th = drop_thresh(p);
     const float ik = 1.0f / (1.0f - p);
     if (x_dtype == DT_BF16)
         hipLaunchKernelGGL(ln_train_kernel<__bf16>, dim3(M), dim3(256), 0, s, (const __bf16*)x, add, add_rows, gamma, beta, eps, y,
-                           sum_out, stat, N, seed, stream, th, ik);
+                           sum_out, stat, N, seed, seed_ctr, stream, th, ik);
     else
         hipLaunchKernelGGL(ln_train_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)x, add, add_rows, gamma, beta, eps, y,
-                           sum_out, stat, N, seed, stream, th, ik);
+                           sum_out, stat, N, seed, seed_ctr, stream, th, ik);
     return hipGetLastError();
 }
 

@@ -214,7 +214,9 @@ class _UNetTrainFn(torch.autograd.Function):
         # draw the same masks; ``_dropout_calls`` travels with resume checkpoints (checkpoint.save_checkpoint)
         import torch.distributed as tdist
         rank = tdist.get_rank() if tdist.is_available() and tdist.is_initialized() else 0
-        seed = (torch.initial_seed() * 0x9E3779B1 + (rank * 0xC2B2AE3D27D4EB4F) + model._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        # (under train.GraphedTrainStep the call counter is added on the device instead: ddimx_set_dropout_counter)
+        calls = 0 if getattr(model, "_dropout_ctr_dev", None) is not None else model._dropout_calls
+        seed = (torch.initial_seed() * 0x9E3779B1 + (rank * 0xC2B2AE3D27D4EB4F) + calls) & 0xFFFFFFFFFFFFFFFF
         tb = _lib.DdimxTables(tables[0].data_ptr(), tables[1].data_ptr(), tables[2].data_ptr())
         _lib.check(lib.ddimx_unet_fwd_train(model._handle, _lib.ptr(model._packed), ctypes.byref(tb), _lib.ptr(ws), ws.numel(),
                                             _lib.ptr(tape), tape.numel(), _lib.ptr(x), _lib.ptr(t), _lib.ptr(out), b, t_len, p, seed,
@@ -546,6 +548,11 @@ class Model(_Node):
                 # backward is ddimx_unet_bwd; dropout as in the reference's train mode (transformers hidden_dropout_prob)
                 self._ensure_packed_bwd(lib, dev)
                 params = [p for _, p in self.named_parameters()]
+                if getattr(self, "_alias_leaves", False):
+                    # train.GraphedTrainStep: differentiate with respect to fresh leaf aliases of the parameters.  autograd keeps
+                    # one AccumulateGrad node per leaf, tied to the stream it was created on and alive as long as any old graph is;
+                    # a stale one from an eager step would make the capture stream hand its gradients to that other stream.
+                    params = self._leaf_aliases = [p.detach().requires_grad_(True) for p in params]
                 return _UNetTrainFn.apply(self, x, tt, (pe, dh, ds), *params)
             out = torch.empty_like(x)
             tt_ptr = self._temb_table.data_ptr() if (not self.training and getattr(self, "_temb_table", None) is not None) else None

@@ -136,6 +136,17 @@ class FusedAdam(optim.Optimizer):
             if tb is None or tb.key != key:
                 tb = self._tables[gi] = _Tables(lists, dev)
             b1, b2 = group["betas"]
+            dyn = getattr(self, "dyn", None)
+            if dyn is not None:
+                # per-step scalars in device memory (train.GraphedTrainStep writes them before every replay)
+                steps.pop()
+                with torch.cuda.device(dev):
+                    _lib.check(lib.ddimx_adam_multi_dyn(_lib.ptr(tb.ptrs[0]), _lib.ptr(tb.ptrs[1]), _lib.ptr(tb.ptrs[2]),
+                                                        _lib.ptr(tb.ptrs[3]), _lib.ptr(tb.sizes), _lib.ptr(tb.bt), _lib.ptr(tb.bo), tb.nblk,
+                                                        None, _lib.ptr(dyn[gi]), float(b1), float(b2), float(group["eps"]),
+                                                        float(group["weight_decay"]), int(group["decoupled"]), _lib.stream()))
+                torch.autograd.graph.increment_version(ps)
+                continue
             with torch.cuda.device(dev):
                 _lib.check(lib.ddimx_adam_multi(_lib.ptr(tb.ptrs[0]), _lib.ptr(tb.ptrs[1]), _lib.ptr(tb.ptrs[2]), _lib.ptr(tb.ptrs[3]),
                                                 _lib.ptr(tb.sizes), _lib.ptr(tb.bt), _lib.ptr(tb.bo), tb.nblk, None, float(group["lr"]),
@@ -145,6 +156,14 @@ class FusedAdam(optim.Optimizer):
             # packed weights) notice, exactly as an in-place torch op would
             torch.autograd.graph.increment_version(ps)
         return loss
+
+
+def adam_step_scalars(group, step):
+    """(lr, 1 - beta1^step, sqrt(1 - beta2^step)) as the fp32 values ``ddimx_adam_multi`` derives from its by-value arguments
+    (betas pass through C floats before the double-precision ``pow``): what ``ddimx_adam_multi_dyn`` reads from device memory."""
+    import numpy as np
+    b1, b2 = (float(np.float32(b)) for b in group["betas"])
+    return (float(np.float32(group["lr"])), float(np.float32(1.0 - b1 ** step)), float(np.float32((1.0 - b2 ** step) ** 0.5)))
 
 
 def get_optimizer(config, parameters):

@@ -59,7 +59,7 @@ def antithetic_timesteps(n, num_timesteps, generator=None):
     return torch.cat([t, num_timesteps - t - 1], dim=0)[:n]
 
 
-def train_step(model, x, state, alphas, e=None, t=None):
+def train_step(model, x, state, alphas, e=None, t=None, _assign_grads=False):
     """One optimisation step (``Diffusion.train_step``, ``runners/diffusion.py:130-173``).  ``x``: [B, C, T, F] on the GPU;
     ``e`` / ``t`` default to fresh noise / antithetic timesteps.  Returns (loss, {clip group: total grad norm}) as device
     tensors."""
@@ -73,7 +73,15 @@ def train_step(model, x, state, alphas, e=None, t=None):
     loss = losses.loss_registry[state.config.model.type](model, x, t, e, alphas)
     for o in state.optimizers.values():
         o.zero_grad()
-    loss.backward()
+    if _assign_grads:
+        # (GraphedTrainStep) the same gradients, taken with respect to the fresh leaf aliases the forward differentiated
+        # (model._alias_leaves) and assigned to the parameters: no AccumulateGrad node of an earlier step is involved
+        params = [p for _, p in model.named_parameters()]
+        for p, g in zip(params, torch.autograd.grad(loss, model._leaf_aliases, allow_unused=True)):
+            p.grad = g
+        model._leaf_aliases = None
+    else:
+        loss.backward()
     norms = {}
     for name, g in state.grad_group.items():
         if g.config.grad_clip is not None:
@@ -87,3 +95,154 @@ def train_step(model, x, state, alphas, e=None, t=None):
     if state.ema_helper is not None:
         state.ema_helper.update(model)
     return loss.detach(), norms
+
+
+class GraphedTrainStep:
+    """``train_step`` replayed from one hipGraph (single rank): forward, loss, backward, clipping, optimizer, EMA -- about
+    1 500 launches -- are captured once and replayed per step, which removes the host's launch cost where it matters (small
+    batches; at 32 samples per GPU the step is GPU-bound either way).
+
+    What changes from step to step is kept out of the graph's frozen kernel arguments: the batch, the noise and the timesteps
+    live in static buffers; each Adam group's (lr, 1 - beta1^step, sqrt(1 - beta2^step)) and the dropout call counter are
+    device scalars written before every replay (``ddimx_adam_multi_dyn``, ``ddimx_set_dropout_counter``), computed on the host
+    exactly as the eager step computes them -- a replayed step is bit-identical to an eager one
+    (tests/test_gpu_train.py::test_graphed_train_step_is_bit_identical_to_eager).  The Python-side state (optimizer step
+    counts, LambdaLR, ``model._dropout_calls``) is advanced per replay, so checkpoints and a later switch back to eager
+    stepping see what an eager run would have left.
+
+    The first ``warmup`` calls run eagerly (they size every workspace and build the optimizer's pointer tables); the next call
+    captures.  Returns ``(loss, norms)`` as device tensors that the NEXT call overwrites.  Only FusedAdam groups (Adam / AdamW /
+    AdaBelief) and a fixed batch shape are supported; data-parallel runs keep the eager step (its all-reduce is staged on
+    events of a side stream)."""
+
+    def __init__(self, model, state, alphas, warmup=2):
+        self.model, self.state, self.alphas = model, state, alphas
+        self.warmup, self.calls, self.graph = max(1, int(warmup)), 0, None
+        self._side = torch.cuda.Stream()
+        for o in state.optimizers.values():
+            if not isinstance(o, optim.FusedAdam):
+                raise NotImplementedError("GraphedTrainStep needs FusedAdam optimizer groups (Adam / AdamW / AdaBelief)")
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            raise NotImplementedError("GraphedTrainStep is single-rank (the data-parallel step overlaps its all-reduce eagerly)")
+
+    # ---- per-step device scalars ------------------------------------------------------------------------------
+    def _groups(self):
+        return [(o, gi, g) for o in self.state.optimizers.values() for gi, g in enumerate(o.param_groups)]
+
+    def _write_scalars(self):
+        """Values of the step about to run: every group's Adam scalars (step count + 1) and the dropout call counter + 1."""
+        vals = []
+        for o, gi, g in self._groups():
+            ps = [p for p in g["params"] if p.grad is not None or p in o.state]
+            step = (o.state[ps[0]]["step"] if ps and o.state[ps[0]] else 0) + 1
+            vals += list(optim.adam_step_scalars(g, step)) + [0.0]
+        self._h_dyn.copy_(torch.tensor(vals, dtype=torch.float32))
+        self._h_ctr[0] = int(getattr(self.model, "_dropout_calls", 0)) + 1
+        self._d_dyn.copy_(self._h_dyn, non_blocking=True)
+        self._d_ctr.copy_(self._h_ctr, non_blocking=True)
+
+    def _advance_host_state(self):
+        """What the captured Python code did to host-side state during capture, once per replay."""
+        for o in self.state.optimizers.values():
+            for g in o.param_groups:
+                for p in g["params"]:
+                    if o.state[p]:
+                        o.state[p]["step"] += 1
+            o._step_count = getattr(o, "_step_count", 0) + 1  # what LambdaLR's call-order check looks at
+        for s in self.state.schedulers.values():
+            s.step()
+        self.model._dropout_calls = int(getattr(self.model, "_dropout_calls", 0)) + 1
+        if hasattr(self.model, "invalidate"):
+            self.model.invalidate()  # the replay updated the parameters through raw pointers
+
+    def _snapshot(self):
+        snap = {"steps": [{p: o.state[p]["step"] for g in o.param_groups for p in g["params"] if o.state[p]}
+                          for o in self.state.optimizers.values()],
+                "lrs": [[g["lr"] for g in o.param_groups] for o in self.state.optimizers.values()],
+                "sched": {k: s.state_dict() for k, s in self.state.schedulers.items()},
+                "calls": int(getattr(self.model, "_dropout_calls", 0))}
+        return snap
+
+    def _restore(self, snap):
+        for o, steps, lrs in zip(self.state.optimizers.values(), snap["steps"], snap["lrs"]):
+            for p, v in steps.items():
+                o.state[p]["step"] = v
+            for g, lr in zip(o.param_groups, lrs):
+                g["lr"] = lr
+        for k, s in self.state.schedulers.items():
+            s.load_state_dict(snap["sched"][k])
+        self.model._dropout_calls = snap["calls"]
+
+    # ---- the step ------------------------------------------------------------------------------------------------
+    def _capture(self, x):
+        from . import _lib
+        dev = x.device
+        ng = len(self._groups())
+        self._h_dyn = torch.empty(4 * ng, dtype=torch.float32).pin_memory()
+        self._h_ctr = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._d_dyn = torch.zeros(4 * ng, dtype=torch.float32, device=dev)
+        self._d_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        k = 0
+        for o in self.state.optimizers.values():
+            o.dyn = [self._d_dyn[4 * (k + gi):4 * (k + gi) + 3] for gi in range(len(o.param_groups))]
+            k += len(o.param_groups)
+        self.model._dropout_ctr_dev = self._d_ctr
+        _lib.check(_lib.load().ddimx_set_dropout_counter(self.model._handle, _lib.ptr(self._d_ctr)))
+        self.x = torch.empty_like(x)
+        self.e = torch.empty_like(x)
+        self.t = torch.zeros(x.size(0), dtype=torch.int64, device=dev)
+        self.alphas = self.alphas.to(dev)
+        snap = self._snapshot()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self.model._alias_leaves = True
+        try:
+            with torch.cuda.graph(g, stream=self._side):
+                self.loss, self.norms = train_step(self.model, self.x, self.state, self.alphas, e=self.e, t=self.t, _assign_grads=True)
+        finally:
+            self.model._alias_leaves = False
+        self._restore(snap)  # capturing ran the host side of one step without executing it
+        self.graph = g
+
+    def close(self):
+        """Back to eager stepping: by-value Adam scalars and dropout seeds again."""
+        from . import _lib
+        for o in self.state.optimizers.values():
+            o.dyn = None
+        if getattr(self.model, "_dropout_ctr_dev", None) is not None:
+            self.model._dropout_ctr_dev = None
+            _lib.check(_lib.load().ddimx_set_dropout_counter(self.model._handle, None))
+        self.graph = None
+
+    def __call__(self, x, e=None, t=None):
+        n = x.size(0)
+        if e is None:
+            e = torch.randn_like(x)
+        if t is None:
+            t = antithetic_timesteps(n, self.alphas.numel())
+        self.calls += 1
+        if self.graph is None and self.calls <= self.warmup:
+            # warm-up on the stream the capture will use: autograd's AccumulateGrad nodes remember the stream they were created
+            # on, and a capture must not be made to wait for another (non-capturing) stream
+            cur = torch.cuda.current_stream(x.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self.model._alias_leaves = True
+                try:
+                    out = train_step(self.model, x, self.state, self.alphas, e=e, t=t, _assign_grads=True)
+                finally:
+                    self.model._alias_leaves = False
+            cur.wait_stream(self._side)
+            return out
+        if self.graph is None:
+            self._capture(x)
+        if x.shape != self.x.shape:
+            raise RuntimeError(f"GraphedTrainStep was captured for batches of shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        self.x.copy_(x, non_blocking=True)
+        self.e.copy_(e, non_blocking=True)
+        self.t.copy_(t.to(torch.int64), non_blocking=True)
+        self._write_scalars()
+        self.graph.replay()
+        self._advance_host_state()
+        return self.loss, self.norms

@@ -76,6 +76,9 @@ const char* ddimx_last_error(void);
  * launch plan.  No device memory is allocated. */
 int ddimx_create(const ddimx_config* cfg, ddimx_handle* out);
 int ddimx_destroy(ddimx_handle h);
+/* Training under hipGraph replay: *counter (device memory, or null to switch off) is added to the dropout seed of every
+ * launch of the training forward / backward when it RUNS; an eager step passes a fresh seed by value instead. */
+int ddimx_set_dropout_counter(ddimx_handle h, const unsigned long long* counter);
 
 /* Number of state_dict entries (388 parameters + temb.te = 389 for configs/audio.yml), in the
  * reference's registration order; name/shape of entry i for cross-checking the host mirror. */
@@ -313,6 +316,13 @@ int ddimx_adam_multi(const long long* param_ptrs, const long long* grad_ptrs, co
                      const long long* v_ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
                      int nblocks, const float* clip, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, int decoupled, void* stream);
+/* The same with the per-step scalars in device memory, dyn = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} (fp32), read when
+ * the kernel RUNS: a training step captured once into a hipGraph is replayed with new values written to dyn between replays
+ * (LambdaLR, functions/__init__.py:53-60, and the bias corrections change every step). */
+int ddimx_adam_multi_dyn(const long long* param_ptrs, const long long* grad_ptrs, const long long* m_ptrs,
+                         const long long* v_ptrs, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                         int nblocks, const float* clip, const float* dyn, float beta1, float beta2, float eps,
+                         float weight_decay, int decoupled, void* stream);
 
 #ifdef __cplusplus
 }

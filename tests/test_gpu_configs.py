@@ -508,3 +508,57 @@ def test_forked_forward_is_bit_identical_for_every_mask(mode):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(ys, ref.flip(0))
+
+
+def test_graphed_train_step_is_bit_identical_to_eager():
+    """train.GraphedTrainStep: two eager warm-up steps, one capture, four replays must leave exactly what six eager steps leave
+    -- parameters, EMA shadow, Adam moments and step counts, LambdaLR state, the dropout call counter -- and return the same
+    losses.  bf16 mode with dropout 0.1 and a 3-step LR warm-up, so the per-step scalars that live in device memory under replay
+    (learning rate, bias corrections, dropout counter) all change between replays."""
+    from ddim_audio_amd import train
+    d = configs.tiny_dict("torch.cuda.BFloat16Tensor")
+    d["optimization"]["optimizer"]["default"]["optimizer"] = "AdamW"
+    d["optimization"]["optimizer"]["default"]["warmup"] = 3
+    cfg = configs.dict2namespace(d)
+    alphas = make_schedule(cfg.diffusion)[1].cuda()
+    n = 6
+    xs = [synth.gaussian(f"graphed.x{i}", (4, 2, 32, 32)).cuda() for i in range(n)]
+    es = [synth.gaussian(f"graphed.e{i}", (4, 2, 32, 32)).cuda() for i in range(n)]
+    ts = [torch.tensor([10 + i, 500, 989 - i, 250]) for i in range(n)]
+
+    def run(graphed):
+        torch.manual_seed(77)
+        m = synth.fill_module(D.Model(cfg), 11)
+        st = train.TrainingState(cfg, m)
+        step = train.GraphedTrainStep(m, st, alphas, warmup=2) if graphed else None
+        losses = []
+        for i in range(n):
+            if graphed:
+                loss, _ = step(xs[i], e=es[i], t=ts[i])
+            else:
+                loss, _ = train.train_step(m, xs[i], st, alphas, e=es[i], t=ts[i])
+            losses.append(float(loss))
+        if graphed:
+            assert step.graph is not None
+            step.close()
+            # back to eager: one more step must continue the same trajectory
+        loss, _ = train.train_step(m, xs[0], st, alphas, e=es[1], t=ts[2])
+        losses.append(float(loss))
+        return m, st, losses
+
+    ma, sa, la = run(False)
+    mb, sb, lb = run(True)
+    assert la == lb, (la, lb)
+    assert ma._dropout_calls == mb._dropout_calls == n + 1
+    for (name, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(a, b), name
+        assert torch.equal(sa.ema_helper.shadow[name], sb.ema_helper.shadow[name]), name
+    for k in sa.optimizers:
+        oa, ob = sa.optimizers[k], sb.optimizers[k]
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+        for pa, pb in zip(oa.param_groups[0]["params"], ob.param_groups[0]["params"]):
+            assert oa.state[pa]["step"] == ob.state[pb]["step"] == n + 1
+            assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+            assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+    for k in sa.schedulers:
+        assert sa.schedulers[k].state_dict()["last_epoch"] == sb.schedulers[k].state_dict()["last_epoch"]

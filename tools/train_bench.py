@@ -2,7 +2,7 @@
 
 Not the headline metric (that is bench.py's sampling rate); reports train samples/s = B / step time for
 `ddim_audio_amd.train.train_step` (loss, backward, clip, fused Adam/AdamW, EMA) on synthetic data.
-usage: python tools/train_bench.py [B] [T] [steps] [dtype: bf16|f32]
+usage: python tools/train_bench.py [B] [T] [steps] [dtype: bf16|f32] [graph]   (graph: also time train.GraphedTrainStep)
 """
 import json
 import os
@@ -54,6 +54,18 @@ def main():
     ev[2].record()
     torch.cuda.synchronize()
     phases = {"fwd_ms": ev[0].elapsed_time(ev[1]), "bwd_ms": ev[1].elapsed_time(ev[2])}
+    if len(sys.argv) > 5 and sys.argv[5] == "graph":  # the same step replayed from one hipGraph
+        for p in m.parameters():
+            p.grad = None
+        gstep = train.GraphedTrainStep(m, state, alphas, warmup=1)
+        for _ in range(3):
+            gstep(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, norms = gstep(x)
+        torch.cuda.synchronize()
+        phases["graphed_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
     flops = 3 * 159.22e9 * (t_len / 1024) * b
     print(json.dumps({"metric": "train samples/s (1 GPU)", "value": b / dtm, "ms_per_step": dtm * 1e3, "B": b, "T": t_len,
                       "dtype": dt, "loss": float(loss), "grad_norm": {k: float(v) for k, v in norms.items()},
