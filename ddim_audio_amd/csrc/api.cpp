@@ -20,11 +20,12 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg;
+    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);
         conv_wps = geti("DDIMX_CONV_WPS", 0);
+        bwd_stats_fused = geti("DDIMX_BWD_STATS_FUSED", 1);  // A/B hook: 0 = GroupNorm-backward statistics by their own pass
         gn_dbg = geti("DDIMX_GN_DBG", 0);  // A/B hook: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
@@ -44,6 +45,8 @@ hipError_t conv_launch_bf16_c3(int, int, int, int, ConvArgs&, hipStream_t);
 hipError_t conv_launch_bf16_du(int, int, int, int, ConvArgs&, hipStream_t);
 hipError_t conv_launch_f32_c3(int, int, int, int, ConvArgs&, hipStream_t);
 hipError_t conv_launch_f32_du(int, int, int, int, ConvArgs&, hipStream_t);
+hipError_t conv_launch_bf16_c3b(int, int, int, int, ConvArgs&, hipStream_t);  // + GroupNorm-backward statistics epilogue
+hipError_t conv_launch_f32_c3b(int, int, int, int, ConvArgs&, hipStream_t);
 
 hipError_t conv_geometry(int dtype, int mode, int cin, int cout, int var, ConvGeom* g) {
     const int nout = mode == UP4 ? 2 * cout : cout;
@@ -53,6 +56,10 @@ hipError_t conv_geometry(int dtype, int mode, int cin, int cout, int var, ConvGe
 }
 hipError_t conv_launch(int dtype, int mode, int cin, int cout, int var, ConvArgs& a, hipStream_t s) {
     const int nout = mode == UP4 ? 2 * cout : cout;
+    if (a.bwd_mode) {
+        if (mode != CONV3 || !a.aux || !a.stats) return hipErrorInvalidValue;
+        return dtype == DT_BF16 ? conv_launch_bf16_c3b(mode, cin, nout, var, a, s) : conv_launch_f32_c3b(mode, cin, nout, var, a, s);
+    }
     if (dtype == DT_BF16)
         return mode == CONV3 ? conv_launch_bf16_c3(mode, cin, nout, var, a, s) : conv_launch_bf16_du(mode, cin, nout, var, a, s);
     return mode == CONV3 ? conv_launch_f32_c3(mode, cin, nout, var, a, s) : conv_launch_f32_du(mode, cin, nout, var, a, s);
@@ -381,6 +388,7 @@ struct ConvCall {
     int B, Hin, Win;
     unsigned long long* stamps = nullptr;
     bool batch_plan = false;  // training: choose the tile variant from the real batch (inference: sample size only)
+    const void* aux = nullptr; const float* aux_scale = nullptr; const float* aux_shift = nullptr; int bwd_mode = 0;  // ConvArgs, same names
     GnIn gn = {};             // gn.stats set: the input's GroupNorm is finished inside the kernel (in_scale / in_shift unused)
     bool groups = false;      // statistics partials in group format (gn_fused.h)
 };
@@ -447,6 +455,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     a.in_scale = q.in_scale; a.in_shift = q.in_shift; a.xf = q.xf; a.act = q.act;
     a.skip = q.skip; a.out = q.out; a.stats = q.stats;
     a.gn = q.gn;
+    a.aux = q.aux; a.aux_scale = q.aux_scale; a.aux_shift = q.aux_shift; a.bwd_mode = q.bwd_mode;
     a.stats_groups_c = q.groups ? q.cout : 0;
     if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
     if (q.groups && q.cout % kGroups) return fail("conv: group-format statistics need cout %% 8 == 0");
@@ -636,11 +645,23 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     CHK(push_colsum(w, sumb, B, C, C, gr.bias1, s));                // conv.1.bias
     // ---- conv.1: weight gradient against GN1(SiLU(u1)), data gradient -> dg
     CHK(run_wgrad(dtype, CONV3, C, C, tp.u1, w.du, tp.sc(1, B, C), tp.sh(1, B, C), XF_SILU_AFFINE, w.partial, gr.w1, B, H, W, s));
+    // The data-gradient convs take the GroupNorm-backward partial sums of their own output in their epilogue (ConvCfg::BWD:
+    // one more read of u1 / x there instead of a pass over dg and u1 / x); the slab count is then the conv's, not resid's.
+    auto fused_stats = [&](ConvCall& d, const void* aux, const float* asc, const float* ash, int mode, int* nparts) -> int {
+        ConvPlan pl;
+        CHK(conv_plan(d, &pl));
+        *nparts = pl.wgs_per_sample * pl.g.classes;
+        if (knobs().bwd_stats_fused == 0 || *nparts > np) { *nparts = 0; return 0; }  // (slabs are sized for resid's partition)
+        d.aux = aux; d.aux_scale = asc; d.aux_shift = ash; d.bwd_mode = mode; d.stats = w.stats;
+        return 0;
+    };
     ConvCall d1 = {dtype, CONV3, C, C, w.du, wd1, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
+    int np1 = 0;
+    CHK(fused_stats(d1, tp.u1, nullptr, nullptr, 1, &np1));
     CHK(run_conv(d1, s, nullptr, nullptr));
     // ---- GN1 (fed by SiLU(u1)) and the SiLU in front of it: du1
-    HIPCHK(gn_bwd_stats_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.stats, B, HW, C, s));
-    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam1, tp.mr(1, B, C), w.coef, dgb1, B, s));
+    if (!np1) { HIPCHK(gn_bwd_stats_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.stats, B, HW, C, s)); np1 = np; }
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np1, C, cnt, gam1, tp.mr(1, B, C), w.coef, dgb1, B, s));
     CHK(push_colsum(w, dgb1, B, 2 * C, C, gr.g1, s));
     CHK(push_colsum(w, dgb1 + C, B, 2 * C, C, gr.b1, s));
     HIPCHK(gn_bwd_apply_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.coef, nullptr, nullptr, w.du, w.sums, B, HW, C, s));
@@ -648,10 +669,12 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     // ---- conv.0: weight gradient against SiLU(GN0(x)), data gradient -> dg
     CHK(run_wgrad(dtype, CONV3, C, C, x, w.du, tp.sc(0, B, C), tp.sh(0, B, C), XF_AFFINE_SILU, w.partial, gr.w0, B, H, W, s));
     ConvCall d0 = {dtype, CONV3, C, C, w.du, wd0, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
+    int np0 = 0;
+    CHK(fused_stats(d0, x, tp.sc(0, B, C), tp.sh(0, B, C), 2, &np0));
     CHK(run_conv(d0, s, nullptr, nullptr));
     // ---- SiLU behind GN0, GN0 itself, and the identity path
-    HIPCHK(gn_bwd_stats_launch(dtype, 1, w.dg, x, tp.sc(0, B, C), tp.sh(0, B, C), w.stats, B, HW, C, s));
-    HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam0, tp.mr(0, B, C), w.coef, dgb0, B, s));
+    if (!np0) { HIPCHK(gn_bwd_stats_launch(dtype, 1, w.dg, x, tp.sc(0, B, C), tp.sh(0, B, C), w.stats, B, HW, C, s)); np0 = np; }
+    HIPCHK(gn_bwd_finalize_launch(w.stats, np0, C, cnt, gam0, tp.mr(0, B, C), w.coef, dgb0, B, s));
     CHK(push_colsum(w, dgb0, B, 2 * C, C, gr.g0, s));
     CHK(push_colsum(w, dgb0 + C, B, 2 * C, C, gr.b0, s));
     HIPCHK(gn_bwd_apply_launch(dtype, 1, w.dg, x, dy, extra, w.coef, tp.sc(0, B, C), tp.sh(0, B, C), dx, nullptr, B, HW, C, s));

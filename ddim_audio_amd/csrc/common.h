@@ -77,6 +77,21 @@ __device__ __forceinline__ f32x2_t silu2(f32x2_t v) {
     r.y = __builtin_amdgcn_rcpf(d.y);
     return v * r;
 }
+// d/du SiLU(u) = s (1 + u (1 - s)), s = sigmoid(u)   (same arithmetic as train_kernels.hip's dsilu_f, two lanes)
+__device__ __forceinline__ f32x2_t dsilu2(f32x2_t u) {
+    const f32x2_t t = u * (-1.4426950408889634f);
+    f32x2_t e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2_t d = e + 1.0f;
+    f32x2_t sg;
+    sg.x = __builtin_amdgcn_rcpf(d.x);
+    sg.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2_t r;
+    r.x = sg.x * fmaf(u.x, 1.0f - sg.x, 1.0f);
+    r.y = sg.y * fmaf(u.y, 1.0f - sg.y, 1.0f);
+    return r;
+}
 __device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) {
     return __builtin_elementwise_fma(a, b, c);
 }

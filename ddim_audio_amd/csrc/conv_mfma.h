@@ -46,6 +46,16 @@ struct ConvArgs {
     void* out;              // [B][Hout][Wout][COUT]
     float* stats;           // [B][nparts][NOUT][2] partial (sum, sumsq) or null; with stats_groups_c > 0 instead
                             // [B][nparts * NOUT/NB][kGroups][2]: the workgroup's partials folded to the 8 groups (gn_fused.h)
+    // Backward-statistics kernels only (ConvCfg::BWD, data-gradient convs of the training step): the GroupNorm-backward partial
+    // sums of the tensor this conv writes, taken in its epilogue instead of by a pass of their own (train_kernels.hip,
+    // gn_bwd_stats).  With f = the value as stored and a = aux at the same position:
+    //   bwd_mode 1 (GroupNorm fed by SiLU(a)):        P += f,                       Q += f * SiLU(a)
+    //   bwd_mode 2 (GroupNorm followed by SiLU):      g = f * SiLU'(a*sc + sh), P += g, Q += g * a     (sc / sh = aux_scale / aux_shift)
+    // stats then holds (P, Q) per channel where the forward kernels hold (sum, sumsq).
+    const void* aux;        // same shape as out
+    const float* aux_scale; // [B][NOUT] (bwd_mode 2)
+    const float* aux_shift;
+    int bwd_mode;
     int stats_groups_c;     // 0, or the real channel count of the output (NOUT / column classes)
     GnIn gn;                // gn.stats != null (and xf != XF_NONE): scale / shift come from the input's group partials,
                             // finished by every workgroup in its prologue, instead of in_scale / in_shift
@@ -60,11 +70,12 @@ struct ConvArgs {
     unsigned long long* stamps;  // diagnostic builds only (-DDDIMX_STAMP): [grid.x][16] per-phase cycle sums
 };
 
-template <typename T, int CIN_, int NOUT_, int NB_, int MODE_, int TH_, int TW_, int WM_, int WN_, int KC_, int TPC_, int OVL_ = 0>
+template <typename T, int CIN_, int NOUT_, int NB_, int MODE_, int TH_, int TW_, int WM_, int WN_, int KC_, int TPC_, int OVL_ = 0, int BWD_ = 0>
 struct ConvCfg {
     typedef T elem;
     static constexpr int CIN = CIN_, NOUT = NOUT_, NB = NB_, MODE = MODE_, TH = TH_, TW = TW_, WM = WM_, WN = WN_,
                          KC = KC_, TPC = TPC_;
+    static constexpr bool BWD = BWD_ != 0;  // separate instantiation with the GroupNorm-backward statistics epilogue
     static constexpr int ES = sizeof(T);
     static constexpr int EPB = 16 / ES;
     static constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
@@ -388,7 +399,21 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     const size_t rowlen = (size_t)a.Wv * NOUT;  // elements per output row (UP4: Wv*2*Cprev = Wout*Cprev)
     const unsigned out_bytes = (unsigned)((size_t)Hout * rowlen * ES);
     const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc((T*)a.out + (size_t)bs * Hout * rowlen, out_bytes);
-    const __amdgpu_buffer_rsrc_t skip_rsrc = make_rsrc(a.skip ? (const T*)a.skip + (size_t)bs * Hout * rowlen : (const T*)a.out, a.skip ? out_bytes : 0u);
+    const void* const side = C::BWD ? a.aux : a.skip;  // the second tensor of the epilogue: skip addend, or aux of the backward statistics
+    const __amdgpu_buffer_rsrc_t skip_rsrc = make_rsrc(side ? (const T*)side + (size_t)bs * Hout * rowlen : (const T*)a.out, side ? out_bytes : 0u);
+    // backward statistics, mode 2: the folded GroupNorm (scale, shift) of this thread's output channels
+    f32x2_t bsc[C::BWD ? NP : 1], bsh[C::BWD ? NP : 1];
+    if constexpr (C::BWD) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { bsc[j] = 1.f; bsh[j] = 0.f; }
+        if (a.bwd_mode == 2 && ovalid) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                bsc[j] = *(const f32x2_t*)(a.aux_scale + (size_t)bs * NOUT + cout0 + oc * EPB + 2 * j);
+                bsh[j] = *(const f32x2_t*)(a.aux_shift + (size_t)bs * NOUT + cout0 + oc * EPB + 2 * j);
+            }
+        }
+    }
 
     // ---- prologue: resident weights (if they fit in one chunk) and the first halo ------------------------
     int wstage = 0;  // ring stage holding the chunk about to be multiplied
@@ -578,9 +603,10 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
         // ---- epilogue 2: coalesced stores of whole pixel rows, + skip, per-channel statistics --------------
         // FULL tiles (entirely inside the image) need no per-lane validity; ragged ones drop stores through the
         // buffer bounds check and mask their statistics.
-        auto epi2 = [&](auto full_tag, auto skip_tag, auto ssilu_tag) __attribute__((always_inline)) {
+        auto epi2 = [&](auto full_tag, auto skip_tag, auto ssilu_tag, auto bwd_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
-            constexpr bool SKIP = decltype(skip_tag)::value;
+            constexpr int BWDM = decltype(bwd_tag)::value;       // 0, or the backward-statistics mode (ConvArgs::bwd_mode)
+            constexpr bool SKIP = decltype(skip_tag)::value || BWDM != 0;  // a second tensor is loaded
             constexpr bool SSILU = decltype(ssilu_tag)::value;  // statistics of SiLU(stored value)
             constexpr int STEP = C::NTHREADS / C::OLPP;          // pixels per pass
             constexpr int NPASS = (C::P + STEP - 1) / STEP;
@@ -608,7 +634,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
                 uint4 v = *(const uint4*)(otile + p * C::OSTRIDE + oc * 16);
                 f32x2_t f[NP];
                 Pairs<T>::unpack(v, f);
-                if (SKIP) {
+                if (SKIP && BWDM == 0) {
                     f32x2_t kk[NP];
                     Pairs<T>::unpack(skv[k], kk);
 #pragma unroll
@@ -618,20 +644,44 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
                 }
                 buf_store16(out_rsrc, offs[k], v);
                 const float msk = vld[k] ? 1.f : 0.f;
+                if constexpr (BWDM != 0) {  // GroupNorm-backward partial sums (P, Q) of the stored gradient against aux
+                    f32x2_t au[NP];
+                    Pairs<T>::unpack(skv[k], au);
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    if (SSILU) f[j] = silu2(f[j]);
-                    if (!FULL) f[j] *= msk;
-                    st_s[j] += f[j];
-                    st_q[j] = fma2(f[j], f[j], st_q[j]);
+                    for (int j = 0; j < NP; ++j) {
+                        f32x2_t g = f[j], vv;
+                        if (BWDM == 1) {
+                            vv = silu2(au[j]);
+                        } else {
+                            g = g * dsilu2(fma2(au[j], bsc[j], bsh[j]));
+                            vv = au[j];
+                        }
+                        if (!FULL) g *= msk;
+                        st_s[j] += g;
+                        st_q[j] = fma2(g, vv, st_q[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        if (SSILU) f[j] = silu2(f[j]);
+                        if (!FULL) f[j] *= msk;
+                        st_s[j] += f[j];
+                        st_q[j] = fma2(f[j], f[j], st_q[j]);
+                    }
                 }
             }
         };
         {
             const bool full = y0 + C::TH <= a.Hv && x0 + C::TW <= a.Wv;  // wave-uniform
-            if (a.act == 2) { if (full) epi2(std::true_type(), std::false_type(), std::true_type()); else epi2(std::false_type(), std::false_type(), std::true_type()); }
-            else if (a.skip) { if (full) epi2(std::true_type(), std::true_type(), std::false_type()); else epi2(std::false_type(), std::true_type(), std::false_type()); }
-            else { if (full) epi2(std::true_type(), std::false_type(), std::false_type()); else epi2(std::false_type(), std::false_type(), std::false_type()); }
+            typedef std::integral_constant<int, 0> B0;
+            if constexpr (C::BWD) {
+                typedef std::integral_constant<int, 1> B1;
+                typedef std::integral_constant<int, 2> B2;
+                if (a.bwd_mode == 1) { if (full) epi2(std::true_type(), std::false_type(), std::false_type(), B1()); else epi2(std::false_type(), std::false_type(), std::false_type(), B1()); }
+                else { if (full) epi2(std::true_type(), std::false_type(), std::false_type(), B2()); else epi2(std::false_type(), std::false_type(), std::false_type(), B2()); }
+            } else if (a.act == 2) { if (full) epi2(std::true_type(), std::false_type(), std::true_type(), B0()); else epi2(std::false_type(), std::false_type(), std::true_type(), B0()); }
+            else if (a.skip) { if (full) epi2(std::true_type(), std::true_type(), std::false_type(), B0()); else epi2(std::false_type(), std::true_type(), std::false_type(), B0()); }
+            else { if (full) epi2(std::true_type(), std::false_type(), std::false_type(), B0()); else epi2(std::false_type(), std::false_type(), std::false_type(), B0()); }
         }
         DDIMX_STAMP_AT(6);
         if (!C::SEPARATE_OUT && t + 1 < t_end) {
