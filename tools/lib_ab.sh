@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of two builds of libddimx on one box: per-op timings, the bench line and single-stream kernel averages.
-# usage: tools/lib_ab.sh OUTDIR   (expects ddim_audio_amd/libddimx_base.so next to libddimx.so)
+# usage: tools/lib_ab.sh OUTDIR   (expects ddim_audio_amd/libddimx_base.so next to libddimx.so: build the commit to compare against
+# -- git stash / git worktree, python -m ddim_audio_amd.build -- and copy its libddimx.so to that name; .so files are git-ignored but
+# travel to the GPU box with the snapshot)
 out=$1; mkdir -p $out
 R=$GRAFT_REPO_ROOT
 for tag in base new base new; do
