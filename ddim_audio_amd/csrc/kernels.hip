@@ -1,6 +1,7 @@
 // Non-MFMA kernels of libddimx: HBM-bound edge convolutions, GroupNorm finalisation, the residual
 // pass, small dense layers, LayerNorm, sampler / loss / EMA elementwise kernels and weight packing.
 // gfx950 only.  Every reduction is a fixed-order tree (no float atomics): results are reproducible.
+#include <stdlib.h>
 #include "kernels.h"
 #include "gn_fused.h"
 
@@ -167,6 +168,124 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
     }
 }
 
+// ---- MFMA path (C0 = 32, cin = 2): the 18-term dot products run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A = weights,
+// rows = cout; B = im2col of the input, columns = 32 consecutive pixels).  MFMA step i multiplies tap i, its two k are the two
+// input channels: lane half h handles channel h (any assignment of the 18 products to (step, half) is valid as long as A and B
+// agree), so the tap geometry is a compile-time constant and the channel one per-lane offset; the bias is a tenth step against
+// a column of ones (exact).  A wave walks 32-pixel blocks; the nine input loads of the block two ahead are issued before the current
+// block is multiplied and stored: the lane-per-pixel kernel above is a chain of {18 loads, wait -- which also waits for the
+// previous stores, vmcnt is in-order -- 576 FMAs, LDS, 4 stores} per 64 pixels and reaches 1.7 TB/s of the 8.  Loads are
+// unconditional (padding taps read the centre pixel and are zeroed by select): a load under a branch is waited for at once.
+template <typename T>
+__global__ void __launch_bounds__(256, 4) conv_in_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, T* __restrict__ out,
+                                                              float* __restrict__ stats, int H, int W, int groups) {
+    constexpr int C0 = 32, CIN = 2, KT = CIN * 9;
+    constexpr int ROWB = C0 * (int)sizeof(T), PCS = ROWB / 16;  // bytes / 16-byte pieces per pixel
+    constexpr int NBLK = kInPixPerBlock / (4 * 32);              // 32-pixel blocks per wave
+    __shared__ float red[4][C0 * 2];
+    __shared__ __attribute__((aligned(16))) char otile[4][32 * (ROWB + 16)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const int HW = H * W;
+    const float* xb = x + (size_t)b * CIN * HW;
+    float wa[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wa[i] = w[l31 * KT + h * 9 + i];
+    const float wbias = h == 0 ? bias[l31] : 0.f;
+    const int hoff = h * HW;  // this lane half's input channel (32-bit element offsets against the uniform base xb)
+    const int wshift = (W & (W - 1)) == 0 ? __builtin_ctz(W) : -1;  // uniform
+    // accumulator register r of a lane holds cout 8*(r/4) + 4*h + r%4 of pixel l31 (32x32 MFMA output layout)
+    float s[16], q[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = q[r] = 0.f;
+    float nxt[2][9];  // the blocks one and two ahead
+    auto load_block = [&](int blk, float (&dst)[9]) __attribute__((always_inline)) {
+        const int p = part * kInPixPerBlock + (blk * 4 + wave) * 32 + l31;
+        const int pc = p < HW ? p : HW - 1;
+        const int py = wshift >= 0 ? pc >> wshift : pc / W, px = pc - py * W;
+        const int ctr = hoff + pc;  // the pixel itself: always a valid element
+        const bool vy[3] = {py > 0, true, py < H - 1}, vx[3] = {px > 0, true, px < W - 1};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int dy = i / 3 - 1, dx = i % 3 - 1;
+            const bool inb = vy[dy + 1] && vx[dx + 1];
+            const float v = xb[inb ? ctr + dy * W + dx : ctr];
+            dst[i] = inb ? v : 0.f;
+        }
+    };
+    load_block(0, nxt[0]);
+    load_block(1, nxt[1]);
+    char* const tile = otile[wave];
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK; ++blk) {
+        const int pix0 = part * kInPixPerBlock + (blk * 4 + wave) * 32;  // first pixel of this block (uniform per wave)
+        if (pix0 >= HW) break;
+        const bool valid = pix0 + l31 < HW;
+        float cur[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { cur[i] = nxt[0][i]; nxt[0][i] = nxt[1][i]; }
+        load_block(blk + 2, nxt[1]);  // (past the workgroup's range / the image: clamped addresses, results unused)
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wbias, 1.0f, acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], cur[i], acc, 0, 0, 0);
+        char* my = tile + l31 * (ROWB + 16);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float f[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+            if constexpr (sizeof(T) == 2) {
+                const uint32_t lo = Piece<__bf16>::pk(f[0], f[1]), hi = Piece<__bf16>::pk(f[2], f[3]);
+                *(uint2*)(my + (8 * qd + 4 * h) * 2) = make_uint2(lo, hi);
+                f[0] = __uint_as_float(lo << 16); f[1] = __uint_as_float(lo & 0xffff0000u);  // the values as stored
+                f[2] = __uint_as_float(hi << 16); f[3] = __uint_as_float(hi & 0xffff0000u);
+            } else {
+                *(float4*)(my + (8 * qd + 4 * h) * 4) = make_float4(f[0], f[1], f[2], f[3]);
+            }
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[4 * qd + j] += f[j]; q[4 * qd + j] = fmaf(f[j], f[j], q[4 * qd + j]); }
+            }
+        }
+        // LDS operations of one wave execute in order: the writes above are visible to the reads below without a fence (a
+        // wavefront-scope fence also waits for the global stores of the previous block)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // the block's 32 pixels are consecutive in memory: PCS / 2 store instructions of 1 KiB contiguous each
+        char* obase = (char*)(out + ((size_t)b * HW + pix0) * C0);
+        const int npix = HW - pix0 < 32 ? HW - pix0 : 32;
+#pragma unroll
+        for (int k = 0; k < PCS / 2; ++k) {
+            const int idx = k * 64 + lane;           // piece index inside the block
+            const int pp = idx / PCS, pc = idx % PCS;
+            const uint4 vv = *(const uint4*)(tile + pp * (ROWB + 16) + pc * 16);
+            if (pp < npix) *(uint4*)(obase + (size_t)idx * 16) = vv;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has been read before the next block overwrites it
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (stats) {
+        // lanes of one half hold the same 16 couts for 32 different pixels: butterflies over the five pixel bits
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { s[r] += __shfl_xor(s[r], o, 64); q[r] += __shfl_xor(q[r], o, 64); }
+            if (l31 == 0) {
+                const int c = 8 * (r / 4) + 4 * h + (r % 4);
+                red[wave][c * 2] = s[r]; red[wave][c * 2 + 1] = q[r];
+            }
+        }
+        __syncthreads();
+        if (groups) {  // group-format partials (gn_fused.h)
+            if (wave == 0) gn_bins_store<4>(&red[0][0], C0 * 2, C0, 0, C0, stats + ((size_t)b * gridDim.x + part) * kGnSlab, lane);
+        } else if (tid < C0 * 2) {
+            stats[(((size_t)b * gridDim.x + part) * C0) * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        }
+    }
+}
+
 hipError_t conv_in_launch(int dtype, const float* x, const float* w, const float* bias, void* out, float* stats, int B,
                           int cin, int C0, int H, int W, hipStream_t s, int groups) {
     const int epb = dtype == DT_BF16 ? 8 : 4;
@@ -174,10 +293,18 @@ hipError_t conv_in_launch(int dtype, const float* x, const float* w, const float
     if (C0 % epb || opp > 64 || (opp & (opp - 1)) || (groups && C0 % kGroups)) return hipErrorInvalidValue;
     dim3 grid(conv_in_nparts(H, W), B);
     if (C0 == 32 && cin == 2) {
+        static const bool lane_per_pixel = getenv("DDIMX_CONV_IN_VALU") != nullptr;  // A/B hook: the round-1 kernel
+        if (lane_per_pixel) {
+            if (dtype == DT_BF16)
+                hipLaunchKernelGGL((conv_in_fast_kernel<__bf16, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (__bf16*)out, stats, H, W, groups);
+            else
+                hipLaunchKernelGGL((conv_in_fast_kernel<float, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (float*)out, stats, H, W, groups);
+            return hipGetLastError();
+        }
         if (dtype == DT_BF16)
-            hipLaunchKernelGGL((conv_in_fast_kernel<__bf16, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (__bf16*)out, stats, H, W, groups);
+            hipLaunchKernelGGL(conv_in_mfma_kernel<__bf16>, grid, dim3(256), 0, s, x, w, bias, (__bf16*)out, stats, H, W, groups);
         else
-            hipLaunchKernelGGL((conv_in_fast_kernel<float, 32, 2>), grid, dim3(256), 0, s, x, w, bias, (float*)out, stats, H, W, groups);
+            hipLaunchKernelGGL(conv_in_mfma_kernel<float>, grid, dim3(256), 0, s, x, w, bias, (float*)out, stats, H, W, groups);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(cin * 9 * C0 + 4 * C0 * 2) * 4;
@@ -259,20 +386,33 @@ __global__ void __launch_bounds__(256) conv_out_fast_kernel(const T* __restrict_
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
     const int y0 = ty * kOutTH, x0 = tx * kOutTW;
-    for (int i = tid; i < IH * IW * CPP; i += 256) {
+    // halo staging: all loads of the tile are issued before the first use, unconditionally (out-of-image pieces read a clamped
+    // address and are zeroed by select) -- under `if (inside) load` every piece was a round trip of its own, six in a row per thread
+    constexpr int NPIECE = IH * IW * CPP, NIT = (NPIECE + 255) / 256;
+    uint4 va[NIT], vb[NIT];
+    bool inb[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i0 = tid + u * 256, i = i0 < NPIECE ? i0 : NPIECE - 1;
         const int c = i % CPP, pix = i / CPP;
         const int gy = y0 - 1 + pix / IW, gx = x0 - 1 + pix % IW;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const size_t g = (((size_t)b * H + gy) * W + gx) * C0 + c * EPB;
-            float f[EPB], k[EPB];
-            Piece<T>::unpack(*(const uint4*)(a + g), f);
-            Piece<T>::unpack(*(const uint4*)(b2 + g), k);
+        inb[u] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+        const size_t g = (((size_t)b * H + gyc) * W + gxc) * C0 + c * EPB;
+        va[u] = *(const uint4*)(a + g);
+        vb[u] = *(const uint4*)(b2 + g);
+    }
 #pragma unroll
-            for (int j = 0; j < EPB; ++j) f[j] += k[j];
-            v = Piece<T>::pack(f);
-        }
-        *(uint4*)(tile + pix * PS + c * 16) = v;
+    for (int u = 0; u < NIT; ++u) {
+        const int i = tid + u * 256;
+        float f[EPB], k[EPB];
+        Piece<T>::unpack(va[u], f);
+        Piece<T>::unpack(vb[u], k);
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) f[j] += k[j];
+        uint4 v = Piece<T>::pack(f);
+        if (!inb[u]) v = make_uint4(0, 0, 0, 0);
+        if (i < NPIECE) *(uint4*)(tile + (i / CPP) * PS + (i % CPP) * 16) = v;
     }
     __syncthreads();
     const int py = tid / kOutTW, px = tid % kOutTW;
