@@ -144,19 +144,33 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs g) {
     }
 }
 
+// (All loads of an element are issued before the first use: the K slices through clamped indices -- at most 8 slices, host
+// cap kMaxSplitK --, absent operands through a valid dummy address, dropped by select.  A loop `for s < splitk: v += load` with a
+// run-time trip count was one load round trip per slice, in a kernel that is nothing but that chain.)
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmArgs g) {
     const long long total = (long long)g.batch * g.M * g.N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int n = i % g.N;
         const long long mz = i / g.N;
         const int m = mz % g.M, z = mz / g.M;
-        float v = 0.f;
-        for (int s = 0; s < g.splitk; ++s) v += g.partial[((size_t)(z * g.splitk + s) * g.M + m) * g.N + n];
         const size_t o = (size_t)z * g.sC + (size_t)m * g.ldc + n;
-        if (g.accumulate) v += g.C[o];
-        if (g.bias) v += g.bias[n];
+        float p[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int sc = s < g.splitk ? s : g.splitk - 1;
+            p[s] = g.partial[((size_t)(z * g.splitk + sc) * g.M + m) * g.N + n];
+        }
+        const float cv = g.C[o];
+        const float bv = (g.bias ? g.bias : g.partial)[n];
+        const float rv = (g.resid ? g.resid : g.C)[o];
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v += s < g.splitk ? p[s] : 0.f;
+        for (int s = 8; s < g.splitk; ++s) v += g.partial[((size_t)(z * g.splitk + s) * g.M + m) * g.N + n];
+        if (g.accumulate) v += cv;
+        if (g.bias) v += bv;
         if (g.act == 1) v = gelu_new_f(v);
-        if (g.resid) v += g.resid[o];
+        if (g.resid) v += rv;
         g.C[o] = v;
     }
 }
@@ -180,10 +194,38 @@ __global__ void __launch_bounds__(256) gemm_reduce_ln_kernel(const GemmArgs g, c
     __shared__ float red[4];
     __shared__ float bc;
     const int m = blockIdx.x, tid = threadIdx.x;
+    // rows of the FNet are 512 wide: elements tid and tid + 256 are loaded -- every K slice, bias, residual, gamma, beta -- before
+    // the first use, unconditionally (clamped indices, dropped by select); wider rows take the general loop for the rest
     float v[8];
     float s = 0.f;
+    float gam[2], bet[2];
+    {
+        float p[2][8], bv[2], rv[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 2; ++i) {
+            const int n0 = tid + i * 256, n = n0 < g.N ? n0 : g.N - 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[i][k] = g.partial[((size_t)(k < g.splitk ? k : g.splitk - 1) * g.M + m) * g.N + n];
+            bv[i] = (g.bias ? g.bias : gamma)[n];
+            rv[i] = (g.resid ? g.resid + (size_t)m * g.ldc : gamma)[n];
+            gam[i] = gamma[n];
+            bet[i] = beta[n];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = tid + i * 256;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += k < g.splitk ? p[i][k] : 0.f;
+            for (int k = 8; k < g.splitk; ++k) t += g.partial[((size_t)k * g.M + m) * g.N + (n < g.N ? n : g.N - 1)];
+            if (g.bias) t += bv[i];
+            if (g.resid) t += rv[i];
+            v[i] = n < g.N ? t : 0.f;
+            s += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 2; i < 8; ++i) {
         const int n = tid + i * 256;
         v[i] = 0.f;
         if (n < g.N) {
@@ -217,7 +259,7 @@ __global__ void __launch_bounds__(256) gemm_reduce_ln_kernel(const GemmArgs g, c
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int n = tid + i * 256;
-        if (n < g.N) out[(size_t)m * g.N + n] = (v[i] - mean) * rstd * gamma[n] + beta[n];
+        if (n < g.N) out[(size_t)m * g.N + n] = (v[i] - mean) * rstd * (i < 2 ? gam[i] : gamma[n]) + (i < 2 ? bet[i] : beta[n]);
     }
 }
 

@@ -870,13 +870,23 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x
     const int m = blockIdx.x, tid = threadIdx.x;
     const TX* xr = x + (size_t)m * N;
     const float* ar = add ? add + (size_t)(m % add_rows) * N : nullptr;
-    float v[8];
+    // every load of the row -- x, the addend, gamma, beta -- is issued before the first use, unconditionally (clamped index,
+    // dropped by select): the kernel is a chain of load round trips and barriers, a load under `if (n < N)` is waited for at once
+    float v[8], gam[8], bet[8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        const int n0 = tid + i * 256, n = n0 < N ? n0 : N - 1;
+        const float xv = to_f<TX>(xr[n]), av = (ar ? ar : gamma)[n];  // (no addend: gamma is read in its place and dropped)
+        v[i] = xv + (ar ? av : 0.f);
+        gam[i] = gamma[n];
+        bet[i] = beta[n];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
         const int n = tid + i * 256;
-        v[i] = 0.f;
-        if (n < N) { v[i] = to_f<TX>(xr[n]) + (ar ? ar[n] : 0.f); s += v[i]; }
+        if (n >= N) v[i] = 0.f;
+        s += v[i];
     }
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -900,7 +910,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int n = tid + i * 256;
-        if (n < N) y[(size_t)m * N + n] = (v[i] - mean) * rstd * gamma[n] + beta[n];
+        if (n < N) y[(size_t)m * N + n] = (v[i] - mean) * rstd * gam[i] + bet[i];
     }
 }
 
