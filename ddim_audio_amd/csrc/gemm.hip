@@ -61,13 +61,26 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs g) {
     const int c1 = (c0 + cper < nchunks_all) ? c0 + cper : nchunks_all;
     const int nk = c1 - c0;
 
+    // Interior tiles of aligned operands with K a multiple of the chunk (every dense GEMM of the FNet): plain 16-byte loads, no
+    // branch around them -- a load under `if (row < rows)` is waited for at once, which made the eight loads of a chunk a chain
+    // of round trips and kept the prefetch below from overlapping the MFMAs.  (uniform per workgroup)
+    const bool full = va && vb && m0 + GBM <= g.M && n0 + GBN <= g.N && g.K % BK == 0;
     float4 ra[LPT], rb[LPT];
     auto load = [&](int k0) __attribute__((always_inline)) {
+        if (full) {
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
-            ra[i] = gemm_ld4(A, m0 + row, g.M, k0 + kq, g.K, g.lda, va);
-            rb[i] = gemm_ld4(B, n0 + row, g.N, k0 + kq, g.K, g.ldb, vb);
+            for (int i = 0; i < LPT; ++i) {
+                const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
+                ra[i] = *(const float4*)(A + (size_t)(m0 + row) * g.lda + k0 + kq);
+                rb[i] = *(const float4*)(B + (size_t)(n0 + row) * g.ldb + k0 + kq);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
+                ra[i] = gemm_ld4(A, m0 + row, g.M, k0 + kq, g.K, g.lda, va);
+                rb[i] = gemm_ld4(B, n0 + row, g.N, k0 + kq, g.K, g.ldb, vb);
+            }
         }
     };
     auto store = [&](int buf) __attribute__((always_inline)) {
@@ -88,16 +101,9 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs g) {
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    if (nk > 0) {
-        load(c0 * BK);
-        store(0);
-    }
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 1 < nk) load((c0 + kc + 1) * BK);
-        const char* pa = sA[kc & 1] + (wm * 32 + l31) * ROWB + h * 16;
-        const char* pb = sB[kc & 1] + (wn * 32 + l31) * ROWB + h * 16;
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+        const char* pa = sA[buf] + (wm * 32 + l31) * ROWB + h * 16;
+        const char* pb = sB[buf] + (wn * 32 + l31) * ROWB + h * 16;
 #pragma unroll
         for (int kg = 0; kg < (BK * (PREC ? 2 : 4)) / 32; ++kg) {  // 32-byte k-groups
             const uint4 a = *(const uint4*)(pa + kg * 32);
@@ -112,8 +118,46 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs g) {
                                                               __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
             }
         }
-        if (kc + 1 < nk) store((kc + 1) & 1);
+    };
+
+    constexpr int NPRE = 4;
+    if (full && nk >= 1 && nk <= NPRE) {
+        // Short K ranges (the split-K slices of the FNet GEMMs are 2-4 chunks): ALL chunks are requested at once -- the kernel is
+        // otherwise one load round trip per chunk, with a microsecond of arithmetic in total.  Chunks past the range re-read the
+        // last one (uniform clamp, no branch around a load) and are not multiplied.
+        float4 qa[NPRE][LPT], qb[NPRE][LPT];
+#pragma unroll
+        for (int c = 0; c < NPRE; ++c) {
+            const int k0 = (c0 + (c < nk ? c : nk - 1)) * BK;
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                const int pc = tid + i * 256, row = pc / F4, kq = (pc % F4) * 4;
+                qa[c][i] = *(const float4*)(A + (size_t)(m0 + row) * g.lda + k0 + kq);
+                qb[c][i] = *(const float4*)(B + (size_t)(n0 + row) * g.ldb + k0 + kq);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NPRE; ++c) {
+            if (c < nk) {  // uniform
+#pragma unroll
+                for (int i = 0; i < LPT; ++i) { ra[i] = qa[c][i]; rb[i] = qb[c][i]; }
+                store(c & 1);
+                __syncthreads();  // (the other buffer's MFMAs finished before the previous barrier)
+                mma(c & 1);
+            }
+        }
+    } else {
+        if (nk > 0) {
+            load(c0 * BK);
+            store(0);
+        }
         __syncthreads();
+        for (int kc = 0; kc < nk; ++kc) {
+            if (kc + 1 < nk) load((c0 + kc + 1) * BK);
+            mma(kc & 1);
+            if (kc + 1 < nk) store((kc + 1) & 1);
+            __syncthreads();
+        }
     }
     // D[row m][col n]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int n = n0 + wn * 32 + l31;
