@@ -383,14 +383,31 @@ __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // everything the later stages read from memory is requested now, ahead of the MFMA block: the sequence-DFT table (staged to
+    // LDS after the MFMAs) and the residual rows of this thread's outputs.  S <= 32: at most 8 table values and 2 outputs per thread.
+    const int j = tid & 15, s0 = tid >> 4;  // stage 2: output frequency j, rows s0 + 16 i
+    float dpre[8], xres[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = tid + u * 256;
+        dpre[u] = dft_seq[i < S * 2 * S ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int sp = s0 + 16 * u;
+        xres[u] = X[((size_t)b * S + (sp < S ? sp : 0)) * hid + blockIdx.x * (MIX_ROWS / 2) + j];
+    }
     constexpr int G = 16;  // 8-float groups per pass: 16 x (A + B) x 4 registers in flight
     for (int g0 = 0; g0 < kq_len / 8; g0 += G) {
         f32x4_t ra[G], rb[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             ra[g] = *(const f32x4_t*)(arow + (g0 + g) * 8);
-            rb[g] = bvalid ? *(const f32x4_t*)(brow + (g0 + g) * 8) : (f32x4_t)(0.f);
+            rb[g] = *(const f32x4_t*)(brow + (g0 + g) * 8);  // rows past S read row 0 and are dropped: no branch around a load
         }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (!bvalid) rb[g] = (f32x4_t)(0.f);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][0], rb[g][0], acc, 0, 0, 0);
@@ -399,7 +416,11 @@ __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][3], rb[g][3], acc, 0, 0, 0);
         }
     }
-    for (int i = tid; i < S * 2 * S; i += 256) dsl[i] = dft_seq[i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = tid + u * 256;
+        if (i < S * 2 * S) dsl[i] = dpre[u];
+    }
     // this wave's partial Ut[32 rows][tokens] -> its LDS slab (D layout of the MFMA: row = (r & 3) + 8 (r >> 2) + 4 h, col = l31)
     float* const mine = part + kq * MIX_ROWS * 33;
 #pragma unroll
@@ -411,17 +432,19 @@ __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__
         part[o] = ((part[o] + part[MIX_ROWS * 33 + o]) + part[2 * MIX_ROWS * 33 + o]) + part[3 * MIX_ROWS * 33 + o];
     }
     __syncthreads();
-    // stage 2: thread = (output frequency j = tid % 16, rows s' = tid / 16 + 16 i); dft_seq row = [cos | -sin]
-    const int j = tid & 15, s0 = tid >> 4;
+    // stage 2: thread = (output frequency j = tid % 16, rows s' = tid / 16 + 16 u); dft_seq row = [cos | -sin]
     const float* uc = part + (2 * j) * 33;
     const float* us = part + (2 * j + 1) * 33;
-    for (int sp = s0; sp < S; sp += 16) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int sp = s0 + 16 * u;
+        if (sp >= S) break;
         const float* dr = dsl + (size_t)sp * 2 * S;
         float a = 0.f;
         for (int s2 = 0; s2 < S; ++s2) a = fmaf(dr[s2], uc[s2], a);
         for (int s2 = 0; s2 < S; ++s2) a = fmaf(dr[S + s2], us[s2], a);
         const size_t o = ((size_t)b * S + sp) * hid + blockIdx.x * (MIX_ROWS / 2) + j;
-        Z[o] = a + X[o];
+        Z[o] = a + xres[u];
     }
 }
 bool fnet_mix_supported(int S, int hid) { return S >= 8 && S <= 32 && S % 8 == 0 && hid % 512 == 0; }
