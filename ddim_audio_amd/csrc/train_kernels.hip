@@ -166,11 +166,22 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
     const int ch = tid & 31, pl = tid >> 5;  // 8 part-lanes per channel
     const int c = g * GS + ch;
     double P = 0.0, Q = 0.0;
-    if (ch < GS) {
-        for (int p = pl; p < nparts; p += 8) {
-            const float* q = stats + (((size_t)b * nparts + p) * C + c) * 2;
-            P += (double)q[0];
-            Q += (double)q[1];
+    {   // eight partials per thread in flight, unconditionally (clamped index, dropped by select), added in the original order: the
+        // loop with a run-time trip count was one load round trip per partial, and this kernel is nothing else
+        const int cs = ch < GS ? c : g * GS;
+        for (int p0 = pl; p0 < nparts; p0 += 64) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + 8 * u;
+                v[u] = *(const float2*)(stats + (((size_t)b * nparts + (p < nparts ? p : nparts - 1)) * C + cs) * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = ch < GS && p0 + 8 * u < nparts;
+                P += in ? (double)v[u].x : 0.0;
+                Q += in ? (double)v[u].y : 0.0;
+            }
         }
     }
     rp[pl][ch] = P; rq[pl][ch] = Q;
@@ -270,8 +281,19 @@ __global__ void __launch_bounds__(256) partsum_kernel(const float* __restrict__ 
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, b = blockIdx.y;
     double s = 0.0;
-    if (c < C)
-        for (int p = rl; p < nparts; p += 8) s += (double)src[(((size_t)b * nparts + p) * C + c) * src_step];
+    {   // eight partials per thread in flight (see gn_bwd_finalize_kernel), same order of addition
+        const int cs = c < C ? c : C - 1;
+        for (int p0 = rl; p0 < nparts; p0 += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + 8 * u;
+                v[u] = src[(((size_t)b * nparts + (p < nparts ? p : nparts - 1)) * C + cs) * src_step];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (c < C && p0 + 8 * u < nparts) ? (double)v[u] : 0.0;
+        }
+    }
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < C) {
