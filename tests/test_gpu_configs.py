@@ -510,14 +510,15 @@ def test_forked_forward_is_bit_identical_for_every_mask(mode):
         assert torch.equal(ys, ref.flip(0))
 
 
-def test_graphed_train_step_is_bit_identical_to_eager():
+@pytest.mark.parametrize("default_opt", ["AdamW", "AdaBelief"])
+def test_graphed_train_step_is_bit_identical_to_eager(default_opt):
     """train.GraphedTrainStep: two eager warm-up steps, one capture, four replays must leave exactly what six eager steps leave
     -- parameters, EMA shadow, Adam moments and step counts, LambdaLR state, the dropout call counter -- and return the same
     losses.  bf16 mode with dropout 0.1 and a 3-step LR warm-up, so the per-step scalars that live in device memory under replay
     (learning rate, bias corrections, dropout counter) all change between replays."""
     from ddim_audio_amd import train
     d = configs.tiny_dict("torch.cuda.BFloat16Tensor")
-    d["optimization"]["optimizer"]["default"]["optimizer"] = "AdamW"
+    d["optimization"]["optimizer"]["default"]["optimizer"] = default_opt  # AdaBelief: the reference's default group (kernel mode 2)
     d["optimization"]["optimizer"]["default"]["warmup"] = 3
     cfg = configs.dict2namespace(d)
     alphas = make_schedule(cfg.diffusion)[1].cuda()
