@@ -114,10 +114,12 @@ def per_kernel_times(model, B, T, reps=20):
     return rows
 
 
-def cpu_baseline(T, B, iters=2):
-    """The CPU oracle (plain PyTorch fp32 restatement, pinned to the reference by golden vectors) on the host cores:
-    ``iters`` DDIM iterations of the SAME workload (batch B, length T) after one small warm-up, plus -- as ``cfg1`` -- one
-    iteration at BASELINE configs[0]'s shape (num_samples = 1, sampling.t_size = 8192: the reference's own CPU-runnable case)."""
+def cpu_baseline(T, B, iters=3):
+    """The CPU oracle (plain PyTorch fp32 restatement, pinned to the reference by golden vectors) on the host cores: one
+    warm-up iteration of the SAME shape, then ``iters`` timed DDIM iterations of the same workload (batch B, length T) --
+    BASELINE.md section 3: >= 3 iterations after one warm-up -- plus, as ``cfg1``, one warm-up and one timed iteration at BASELINE
+    configs[0]'s shape (num_samples = 1, sampling.t_size = 8192: the reference's own CPU-runnable case; its 100 steps are
+    extrapolated from that iteration, every iteration costs the same)."""
     from ddim_audio_amd import configs, schedule, synth
     from ddim_audio_amd.model import state_inventory
     from oracle import ref_cpu
@@ -138,13 +140,50 @@ def cpu_baseline(T, B, iters=2):
         return time.perf_counter() - t0
 
     with torch.no_grad():
-        ref_cpu.model_forward(sd, cfg, torch.randn(1, 2, 64, 256), torch.tensor([10]))  # warm-up
+        leg(B, T, 1)  # warm-up at the timed shape (allocator, oneDNN primitive caches, thread pool)
         dt = leg(B, T, iters)
+        leg(1, 8192, 1)
         dt1 = leg(1, 8192, 1)
     return dict(value=B * iters / dt, unit="sample-fwd/s", cores=cores, kind="port",
-                sample=f"{iters} DDIM iterations x batch {B} at T={T} (oracle/ref_cpu.py, fp32, {cores} threads), {dt:.1f} s",
-                cfg1=dict(value=1.0 / dt1, unit="sample-fwd/s", t1024_equivalents_per_s=8.0 / dt1,
-                          sample=f"1 DDIM iteration x batch 1 at T=8192 (BASELINE configs[0] shape), {dt1:.1f} s"))
+                sample=f"{iters} DDIM iterations x batch {B} at T={T} after one same-shape warm-up iteration (oracle/ref_cpu.py, fp32, "
+                       f"{cores} threads), {dt:.1f} s",
+                cfg1=dict(value=1.0 / dt1, unit="sample-fwd/s", t1024_equivalents_per_s=8.0 / dt1, seconds_for_100_steps=100.0 * dt1,
+                          sample=f"1 DDIM iteration x batch 1 at T=8192 after one warm-up (BASELINE configs[0] shape), {dt1:.1f} s"))
+
+
+def sampler_leg(cfg_strs, B, T, steps, seed=4321):
+    """A secondary measurement of the same loop on another configuration (never the headline ``value``): a fresh model, the
+    1000-step eta = 0 schedule, one hipGraph per step; 3 warm-up steps, ``steps`` timed ones.  Returns sample-fwd/s."""
+    import ddim_audio_amd as D
+    from ddim_audio_amd import configs, schedule, synth
+    from ddim_audio_amd.sampler import DDIMStepper
+    try:
+        cfg = configs.audio_config(*cfg_strs)
+        model = synth.fill_module(D.Model(cfg)).eval()
+        alphas = schedule.make_schedule(cfg.diffusion)[1]
+        n_sched = cfg.diffusion.num_diffusion_timesteps
+        coef = schedule.ddim_coefficients(schedule.make_seq(n_sched, n_sched), alphas, 0.0)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        x = torch.randn(B, 2, T, cfg.model.f_size, device="cuda", generator=g)
+        with torch.no_grad():
+            st = DDIMStepper(model, x, coef)
+            for _ in range(3):
+                st.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                st.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ok = bool(torch.isfinite(x).all().item())
+            st.close()
+        del st, model, x
+        torch.cuda.empty_cache()
+        return {"value": B * steps / dt, "unit": "sample-fwd/s", "batch": B, "t_size": T, "steps": steps, "ms_per_step": dt / steps * 1e3,
+                "output_finite": ok}
+    except Exception as ex:  # the headline measurement must survive a failure here
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
 def training_leg(args, cfg, dev, rank, world, backend, steps=3):
@@ -218,7 +257,7 @@ def training_leg(args, cfg, dev, rank, world, backend, steps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=1000, help="timed iterations (default: the whole 1000-step sample, ~4 s)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="spectrograms per GPU (weak scaling)")
     ap.add_argument("--t-size", type=int, default=1024)
@@ -229,6 +268,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the secondary sampler legs (batch 32; mixed fp32-FNet mode)")
     ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU of the training leg (BASELINE config 4)")
     args = ap.parse_args()
 
@@ -322,6 +362,23 @@ def main():
         assert full.size(0) == world * B
         del full
 
+    ranks_seen = None
+    if world > 1:  # an independent count of the ranks the collective backend really connects: all-reduce of ones
+        one = torch.ones(1, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
+
+    extra = {}
+    if world == 1 and not args.no_extra_legs and os.environ.get("DDIMX_BENCH_EXTRA", "1") != "0":
+        stepper.close()
+        # north_star's own batch ("... steps/sec at batch 32 on 1x MI355X"), same dtype mode as the headline
+        extra["b32"] = sampler_leg((tstr, fstr), 32, T, 60)
+        # the reference's own half-precision mode: bf16 convolutions, fp32 transformer (models/diffusion.py:242-246; fftn has no
+        # bf16, so this is its only workable half setup) at the headline batch
+        if args.dtype == "bf16":
+            extra["mixed"] = sampler_leg((tstr, "torch.cuda.FloatTensor"), B, T, 200)
+            extra["mixed"]["fnet_dtype"] = "f32"
+
     train_leg = None
     if not args.no_train_leg and os.environ.get("DDIMX_BENCH_TRAIN", "1") != "0":
         train_leg = training_leg(args, cfg, dev, rank, world, backend)
@@ -334,6 +391,7 @@ def main():
             "unit": "sample-fwd/s",
             "n_gpus": world,
             "ranks": world,  # torch.distributed world size (RCCL ranks, one per GPU); 1 = no process group
+            "rccl_ranks_seen": ranks_seen,  # sum over ranks of 1 through the collective backend (None at N = 1)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -397,6 +455,8 @@ def main():
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(T, B)
+        for k, v in extra.items():
+            out[k] = v
         if train_leg is not None:
             out["train_step"] = train_leg
         print(json.dumps(out), flush=True)

@@ -85,6 +85,10 @@ _SIGS = {
     "ddimx_conv_out_fwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "ddimx_fnet_fwd": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int,
                                c_void_p]),
+    "ddimx_fnet_fwd_train": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
+                                     c_void_p, c_int, c_int, c_float, c_ulonglong, c_void_p]),
+    "ddimx_fnet_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, c_void_p]),
     "ddimx_downup_bwd_workspace_bytes": (c_longlong, [c_int] * 6),
     "ddimx_downsample_bwd": (c_int, [c_int] * 3 + [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "ddimx_upsample_add_bwd": (c_int, [c_int] * 3 + [c_void_p] * 7 + [c_int] * 3 + [c_void_p]),

@@ -1206,6 +1206,101 @@ static int fourier_mix(const ddimx_ctx* c, const ddimx_tables* tb, const TrainWs
     return 0;
 }
 
+// Transformer_Module in training mode (models/diffusion.py:148-167 with the FNet layers of modeling_fnet.py:138-279): tokens
+// `x` (NHWC bottleneck activation = [B*S][width] rows) -> w.O [B*S][width] fp32, keeping the tape rows the backward needs.
+static int fnet_fwd_train_part(const ddimx_ctx* c, const void* packed, const ddimx_tables* tables, const TrainWs& w, const TrainTape& tp,
+                               const void* x, int B, int S, float dropout_p, unsigned long long seed, hipStream_t s) {
+    const ddimx_config& f = c->cfg;
+    const int dt = c->dtype;
+    const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
+    const float eps_ln = f.fnet_ln_eps;
+    const int bf = c->fnet_bf16;
+    HIPCHK(ln_train_launch(dt, x, tables->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps_ln, tp.ln0, nullptr,
+                           tp.ln0_stat, M, width, 0.f, seed, 0, s, c->dropout_ctr));
+    CHK(tgemm(w, s, tp.ln0, pf(c, packed, c->proj_w), tp.X0, M, hid, width, pf(c, packed, c->proj_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
+    if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(tp.X0, tp.X0, (long long)M * hid, dropout_p, seed, 0, s, c->dropout_ctr));
+    const float* xc = tp.X0;
+    for (int i = 0; i < f.fnet_layers; ++i) {
+        const ddimx_ctx::FL& Lw = c->fl[i];
+        const TrainTape::FLT& q = tp.fl[i];
+        CHK(fourier_mix(c, tables, w, xc, q.Z, B, S, s));
+        HIPCHK(ln_train_launch(DT_F32, q.Z, nullptr, 1, pf(c, packed, Lw.ln1_w), pf(c, packed, Lw.ln1_b), eps_ln, q.Y1, nullptr,
+                               q.zstat, M, hid, 0.f, seed, 0, s, c->dropout_ctr));
+        CHK(tgemm(w, s, q.Y1, pf(c, packed, Lw.w1), q.pre, M, inter, hid, pf(c, packed, Lw.b1), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
+        HIPCHK(gelu_launch(q.pre, nullptr, w.Hb, (long long)M * inter, 0, s));
+        CHK(tgemm(w, s, w.Hb, pf(c, packed, Lw.w2), w.dXa, M, hid, inter, pf(c, packed, Lw.b2), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
+        HIPCHK(ln_train_launch(DT_F32, w.dXa, q.Y1, M, pf(c, packed, Lw.ln2_w), pf(c, packed, Lw.ln2_b), eps_ln, q.Xout, q.s,
+                               q.sstat, M, hid, dropout_p, seed, (unsigned)(i + 1), s, c->dropout_ctr));
+        xc = q.Xout;
+    }
+    CHK(tgemm(w, s, xc, pf(c, packed, c->cout_w), w.O, M, width, hid, pf(c, packed, c->cout_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
+    return 0;
+}
+
+// Backward of the Transformer_Module: w.dO [B*S][width] fp32 (gradient of its output) -> every transformer.* parameter gradient
+// (written at its plan offset of `grads`) and w.dTok [B*S][width] fp32 (gradient of its input tokens `x`).
+static int fnet_bwd_part(const ddimx_ctx* c, const void* packed, const char* pb, const BwdPack& bp, const ddimx_tables* tables,
+                         const TrainWs& w, const TrainTape& tp, const void* Dlast, float* grads, const std::vector<long long>& goff,
+                         int B, int S, float dropout_p, unsigned long long seed, hipStream_t s) {
+    const ddimx_config& f = c->cfg;
+    const int dt = c->dtype;
+    const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
+    const int bf = c->fnet_bf16;
+    const int C5 = f.ch[c->L - 1], Fr = c->Fr;
+    auto G = [&](int i) { return grads + goff[i]; };
+    {   // compute_out: O = Xlast Wc^T + bc   (parameters live in the token-order permutation; gradients are un-permuted)
+        const float* Xlast = f.fnet_layers ? tp.fl[f.fnet_layers - 1].Xout : tp.X0;
+        HIPCHK(colsum_launch(w.dO, M, width, width, w.pgrad, s));
+        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->cout_b), 1, Fr, C5, s));
+        HIPCHK(transpose_launch(w.dO, w.T1, M, width, 0, s));
+        HIPCHK(transpose_launch(Xlast, w.T2, M, hid, 0, s));
+        CHK(tgemm(w, s, w.T1, w.T2, w.pgrad, width, hid, M, nullptr, nullptr, bf));
+        HIPCHK(pack_perm_rows_launch(w.pgrad, G(c->cout_w), Fr, C5, hid, s));
+        CHK(tgemm(w, s, w.dO, (const float*)(pb + bp.coutT), w.dXa, M, hid, width, nullptr, nullptr, bf));
+    }
+    for (int i = f.fnet_layers - 1; i >= 0; --i) {
+        const ddimx_ctx::FL& Lw = c->fl[i];
+        const TrainTape::FLT& q = tp.fl[i];
+        // output.LayerNorm(s), s = Y1 + dropout(FFN)
+        HIPCHK(ln_bwd_launch(DT_F32, w.dXa, q.s, nullptr, 1, q.sstat, pf(c, packed, Lw.ln2_w), w.dXb, w.lnpart, G(Lw.ln2_w), G(Lw.ln2_b),
+                             M, hid, s));
+        const float* dO2 = w.dXb;
+        if (dropout_p > 0.f) {
+            HIPCHK(dropout_apply_launch(w.dXb, w.dZ, (long long)M * hid, dropout_p, seed, (unsigned)(i + 1), s, c->dropout_ctr));
+            dO2 = w.dZ;
+        }
+        HIPCHK(colsum_launch(dO2, M, hid, hid, G(Lw.b2), s));
+        HIPCHK(transpose_launch(dO2, w.T1, M, hid, 0, s));
+        HIPCHK(transpose_launch(q.pre, w.T2, M, inter, 1, s));                                   // gelu(pre)^T
+        CHK(tgemm(w, s, w.T1, w.T2, G(Lw.w2), hid, inter, M, nullptr, nullptr, bf));             // dW2 [hid][inter]
+        CHK(tgemm(w, s, dO2, (const float*)(pb + bp.w2T[i]), w.dH, M, inter, hid, nullptr, nullptr, bf));
+        HIPCHK(gelu_launch(w.dH, q.pre, w.dH, (long long)M * inter, 1, s));                      // d(pre)
+        HIPCHK(colsum_launch(w.dH, M, inter, inter, G(Lw.b1), s));
+        HIPCHK(transpose_launch(w.dH, w.T1, M, inter, 0, s));
+        HIPCHK(transpose_launch(q.Y1, w.T2, M, hid, 0, s));
+        CHK(tgemm(w, s, w.T1, w.T2, G(Lw.w1), inter, hid, M, nullptr, nullptr, bf));             // dW1 [inter][hid]
+        CHK(tgemm(w, s, w.dH, (const float*)(pb + bp.w1T[i]), w.dXa, M, hid, inter, nullptr, w.dXb, bf));  // dY1 = ds + dpre W1
+        // fourier.output.LayerNorm(Z), Z = X + Re(FFT2(X))
+        HIPCHK(ln_bwd_launch(DT_F32, w.dXa, q.Z, nullptr, 1, q.zstat, pf(c, packed, Lw.ln1_w), w.dXb, w.lnpart, G(Lw.ln1_w), G(Lw.ln1_b),
+                             M, hid, s));
+        CHK(fourier_mix(c, tables, w, w.dXb, w.dXa, B, S, s));
+    }
+    {   // embedding: X0 = dropout(LN0(tok + posenc) Wp^T + bp)
+        if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(w.dXa, w.dXa, (long long)M * hid, dropout_p, seed, 0, s, c->dropout_ctr));
+        HIPCHK(colsum_launch(w.dXa, M, hid, hid, G(c->proj_b), s));
+        HIPCHK(transpose_launch(w.dXa, w.T1, M, hid, 0, s));
+        HIPCHK(transpose_launch(tp.ln0, w.T2, M, width, 0, s));
+        CHK(tgemm(w, s, w.T1, w.T2, w.pgrad, hid, width, M, nullptr, nullptr, bf));
+        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->proj_w), hid, Fr, C5, s));
+        CHK(tgemm(w, s, w.dXa, (const float*)(pb + bp.projT), w.dO, M, width, hid, nullptr, nullptr, bf));
+        HIPCHK(ln_bwd_launch(dt, w.dO, Dlast, tables->posenc, S, tp.ln0_stat, pf(c, packed, c->ln0_w), w.dTok, w.lnpart, w.pgrad,
+                             w.pgrad + width, M, width, s));
+        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->ln0_w), 1, Fr, C5, s));
+        HIPCHK(pack_perm_cols_launch(w.pgrad + width, G(c->ln0_b), 1, Fr, C5, s));
+    }
+    return 0;
+}
+
 static inline int down_bi(const ddimx_config& f, int l, int r) { int b = 0; for (int i = 0; i < l; ++i) b += f.res[i]; return b + r; }
 static inline int up_bi(const ddimx_config& f, int L, int l, int r) { int b = 0; for (int i = L - 1; i > l; --i) b += f.res[i]; return b + r; }
 
@@ -1332,28 +1427,7 @@ int ddimx_unet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables*
     }
     // bottleneck (models/diffusion.py:267-279), training mode: dropout after the projection and after each FFN
     const int S = T >> (L - 1), CL = f.ch[L - 1];
-    const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
-    const float eps_ln = f.fnet_ln_eps;
-    const int bf = c->fnet_bf16;
-    HIPCHK(ln_train_launch(dt, cur, tables->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps_ln, tp.ln0, nullptr,
-                           tp.ln0_stat, M, width, 0.f, seed, 0, s, c->dropout_ctr));
-    CHK(tgemm(w, s, tp.ln0, pf(c, packed, c->proj_w), tp.X0, M, hid, width, pf(c, packed, c->proj_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
-    if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(tp.X0, tp.X0, (long long)M * hid, dropout_p, seed, 0, s, c->dropout_ctr));
-    const float* xc = tp.X0;
-    for (int i = 0; i < f.fnet_layers; ++i) {
-        const ddimx_ctx::FL& Lw = c->fl[i];
-        const TrainTape::FLT& q = tp.fl[i];
-        CHK(fourier_mix(c, tables, w, xc, q.Z, B, S, s));
-        HIPCHK(ln_train_launch(DT_F32, q.Z, nullptr, 1, pf(c, packed, Lw.ln1_w), pf(c, packed, Lw.ln1_b), eps_ln, q.Y1, nullptr,
-                               q.zstat, M, hid, 0.f, seed, 0, s, c->dropout_ctr));
-        CHK(tgemm(w, s, q.Y1, pf(c, packed, Lw.w1), q.pre, M, inter, hid, pf(c, packed, Lw.b1), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
-        HIPCHK(gelu_launch(q.pre, nullptr, w.Hb, (long long)M * inter, 0, s));
-        CHK(tgemm(w, s, w.Hb, pf(c, packed, Lw.w2), w.dXa, M, hid, inter, pf(c, packed, Lw.b2), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
-        HIPCHK(ln_train_launch(DT_F32, w.dXa, q.Y1, M, pf(c, packed, Lw.ln2_w), pf(c, packed, Lw.ln2_b), eps_ln, q.Xout, q.s,
-                               q.sstat, M, hid, dropout_p, seed, (unsigned)(i + 1), s, c->dropout_ctr));
-        xc = q.Xout;
-    }
-    CHK(tgemm(w, s, xc, pf(c, packed, c->cout_w), w.O, M, width, hid, pf(c, packed, c->cout_b), nullptr, bf, 1, 0, 0, 0, -1, -1, S));
+    CHK(fnet_fwd_train_part(c, packed, tables, w, tp, cur, B, S, dropout_p, seed, s));
     HIPCHK(resid_launch(dt, cur, w.O, 1, nullptr, nullptr, tp.up_in[L - 1], w.stats, B, S * c->Fr, CL, s));
     np = resid_nparts(dt, S * c->Fr, CL); cs = CL;
     for (int l = L - 1; l >= 0; --l) {
@@ -1496,61 +1570,10 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
     }
     // ---- bottleneck: up_in[L-1] = D_{L-1} + O
     const int S = T >> (L - 1), CL = f.ch[L - 1];
-    const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
-    const int bf = c->fnet_bf16;
-    const int C5 = CL, Fr = c->Fr;
+    const int width = c->width, M = B * S, Fr = c->Fr;
     const void* Dlast = tp.dn_y[L - 1].back();
     HIPCHK(cast_f32_launch(dt, w.GS[L - 1], w.dO, (long long)M * width, s));
-    {   // compute_out: O = Xlast Wc^T + bc   (parameters live in the token-order permutation; gradients are un-permuted)
-        const float* Xlast = f.fnet_layers ? tp.fl[f.fnet_layers - 1].Xout : tp.X0;
-        HIPCHK(colsum_launch(w.dO, M, width, width, w.pgrad, s));
-        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->cout_b), 1, Fr, C5, s));
-        HIPCHK(transpose_launch(w.dO, w.T1, M, width, 0, s));
-        HIPCHK(transpose_launch(Xlast, w.T2, M, hid, 0, s));
-        CHK(tgemm(w, s, w.T1, w.T2, w.pgrad, width, hid, M, nullptr, nullptr, bf));
-        HIPCHK(pack_perm_rows_launch(w.pgrad, G(c->cout_w), Fr, C5, hid, s));
-        CHK(tgemm(w, s, w.dO, (const float*)(pb + bp.coutT), w.dXa, M, hid, width, nullptr, nullptr, bf));
-    }
-    for (int i = f.fnet_layers - 1; i >= 0; --i) {
-        const ddimx_ctx::FL& Lw = c->fl[i];
-        const TrainTape::FLT& q = tp.fl[i];
-        // output.LayerNorm(s), s = Y1 + dropout(FFN)
-        HIPCHK(ln_bwd_launch(DT_F32, w.dXa, q.s, nullptr, 1, q.sstat, pf(c, packed, Lw.ln2_w), w.dXb, w.lnpart, G(Lw.ln2_w), G(Lw.ln2_b),
-                             M, hid, s));
-        const float* dO2 = w.dXb;
-        if (dropout_p > 0.f) {
-            HIPCHK(dropout_apply_launch(w.dXb, w.dZ, (long long)M * hid, dropout_p, seed, (unsigned)(i + 1), s, c->dropout_ctr));
-            dO2 = w.dZ;
-        }
-        HIPCHK(colsum_launch(dO2, M, hid, hid, G(Lw.b2), s));
-        HIPCHK(transpose_launch(dO2, w.T1, M, hid, 0, s));
-        HIPCHK(transpose_launch(q.pre, w.T2, M, inter, 1, s));                                   // gelu(pre)^T
-        CHK(tgemm(w, s, w.T1, w.T2, G(Lw.w2), hid, inter, M, nullptr, nullptr, bf));             // dW2 [hid][inter]
-        CHK(tgemm(w, s, dO2, (const float*)(pb + bp.w2T[i]), w.dH, M, inter, hid, nullptr, nullptr, bf));
-        HIPCHK(gelu_launch(w.dH, q.pre, w.dH, (long long)M * inter, 1, s));                      // d(pre)
-        HIPCHK(colsum_launch(w.dH, M, inter, inter, G(Lw.b1), s));
-        HIPCHK(transpose_launch(w.dH, w.T1, M, inter, 0, s));
-        HIPCHK(transpose_launch(q.Y1, w.T2, M, hid, 0, s));
-        CHK(tgemm(w, s, w.T1, w.T2, G(Lw.w1), inter, hid, M, nullptr, nullptr, bf));             // dW1 [inter][hid]
-        CHK(tgemm(w, s, w.dH, (const float*)(pb + bp.w1T[i]), w.dXa, M, hid, inter, nullptr, w.dXb, bf));  // dY1 = ds + dpre W1
-        // fourier.output.LayerNorm(Z), Z = X + Re(FFT2(X))
-        HIPCHK(ln_bwd_launch(DT_F32, w.dXa, q.Z, nullptr, 1, q.zstat, pf(c, packed, Lw.ln1_w), w.dXb, w.lnpart, G(Lw.ln1_w), G(Lw.ln1_b),
-                             M, hid, s));
-        CHK(fourier_mix(c, tables, w, w.dXb, w.dXa, B, S, s));
-    }
-    {   // embedding: X0 = dropout(LN0(tok + posenc) Wp^T + bp)
-        if (dropout_p > 0.f) HIPCHK(dropout_apply_launch(w.dXa, w.dXa, (long long)M * hid, dropout_p, seed, 0, s, c->dropout_ctr));
-        HIPCHK(colsum_launch(w.dXa, M, hid, hid, G(c->proj_b), s));
-        HIPCHK(transpose_launch(w.dXa, w.T1, M, hid, 0, s));
-        HIPCHK(transpose_launch(tp.ln0, w.T2, M, width, 0, s));
-        CHK(tgemm(w, s, w.T1, w.T2, w.pgrad, hid, width, M, nullptr, nullptr, bf));
-        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->proj_w), hid, Fr, C5, s));
-        CHK(tgemm(w, s, w.dXa, (const float*)(pb + bp.projT), w.dO, M, width, hid, nullptr, nullptr, bf));
-        HIPCHK(ln_bwd_launch(dt, w.dO, Dlast, tables->posenc, S, tp.ln0_stat, pf(c, packed, c->ln0_w), w.dTok, w.lnpart, w.pgrad,
-                             w.pgrad + width, M, width, s));
-        HIPCHK(pack_perm_cols_launch(w.pgrad, G(c->ln0_w), 1, Fr, C5, s));
-        HIPCHK(pack_perm_cols_launch(w.pgrad + width, G(c->ln0_b), 1, Fr, C5, s));
-    }
+    CHK(fnet_bwd_part(c, packed, pb, bp, tables, w, tp, Dlast, grads, goff, B, S, dropout_p, seed, s));
     if (n_events) HIPCHK(hipEventRecord((hipEvent_t)bucket_events[1], s));  // bucket 1: transformer.* gradients are final
     // d(D_{L-1}) = skip gradient + gradient through the bottleneck
     HIPCHK(resid_launch(dt, w.GS[L - 1], w.dTok, 1, nullptr, nullptr, w.Ga[L - 1], nullptr, B, S * Fr, CL, s));
@@ -1763,6 +1786,60 @@ int ddimx_fnet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* table
 }
 
 // ---- backward twins of the per-op forwards (the whole-network backward runs exactly these launches) ---------------------
+// Transformer_Module alone, training mode + its backward (the `_bwd` twin of ddimx_fnet_fwd).  Both use the whole-network
+// scratch / tape layouts (ddimx_train_workspace_bytes, ddimx_train_tape_bytes for the same B, T) and run exactly the launches
+// ddimx_unet_fwd_train / ddimx_unet_bwd issue for the bottleneck.
+int ddimx_fnet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
+                         void* tape, long long tape_bytes, const void* x, float* out, int B, int T, float dropout_p,
+                         unsigned long long seed, void* stream) {
+    if (!h || !packed || !tables || !workspace || !tape || !x || !out) return fail("ddimx_fnet_fwd_train: null argument");
+    const ddimx_ctx* c = h;
+    const int L = c->L;
+    if (B < 1 || T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("ddimx_fnet_fwd_train: bad shape B=%d T=%d", B, T);
+    if (dropout_p < 0.f || dropout_p >= 1.f) return fail("dropout probability %g out of [0, 1)", (double)dropout_p);
+    TrainWs w;
+    carve_train_ws(c, (char*)workspace, B, T, &w);
+    if ((long long)w.total > workspace_bytes) return fail("training workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
+    TrainTape tp;
+    carve_tape(c, (char*)tape, B, T, &tp);
+    if ((long long)tp.total > tape_bytes) return fail("tape too small: need %zu bytes, got %lld", tp.total, tape_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int S = T >> (L - 1);
+    CHK(fnet_fwd_train_part(c, packed, tables, w, tp, x, B, S, dropout_p, seed, s));
+    HIPCHK(hipMemcpyAsync(out, w.O, (size_t)B * S * c->width * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+int ddimx_fnet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                   long long workspace_bytes, const void* tape, long long tape_bytes, const void* x, const float* d_out, float* d_x,
+                   float* grads, int B, int T, float dropout_p, unsigned long long seed, void* stream) {
+    if (!h || !packed || !packed_bwd || !tables || !workspace || !tape || !x || !d_out || !d_x || !grads)
+        return fail("ddimx_fnet_bwd: null argument");
+    const ddimx_ctx* c = h;
+    const int L = c->L;
+    if (B < 1 || T < (1 << (L - 1)) || T % (1 << (L - 1))) return fail("ddimx_fnet_bwd: bad shape B=%d T=%d", B, T);
+    if (dropout_p < 0.f || dropout_p >= 1.f) return fail("dropout probability %g out of [0, 1)", (double)dropout_p);
+    TrainWs w;
+    carve_train_ws(c, (char*)workspace, B, T, &w);
+    if ((long long)w.total > workspace_bytes) return fail("training workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
+    TrainTape tp;
+    carve_tape(c, (char*)const_cast<void*>(tape), B, T, &tp);
+    if ((long long)tp.total > tape_bytes) return fail("tape too small: need %zu bytes, got %lld", tp.total, tape_bytes);
+    BwdPack bp;
+    plan_bwd_pack(c, &bp);
+    std::vector<long long> goff(c->specs.size());
+    {
+        long long n = 0;
+        for (size_t i = 0; i < c->specs.size(); ++i) { goff[i] = n; n += (c->specs[i].numel + 63) & ~63ll; }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int S = T >> (L - 1);
+    const size_t bytes = (size_t)B * S * c->width * 4;
+    HIPCHK(hipMemcpyAsync(w.dO, d_out, bytes, hipMemcpyDeviceToDevice, s));
+    CHK(fnet_bwd_part(c, packed, (const char*)packed_bwd, bp, tables, w, tp, x, grads, goff, B, S, dropout_p, seed, s));
+    HIPCHK(hipMemcpyAsync(d_x, w.dTok, bytes, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 struct DuBwdWs { float *partial, *stats, *dgb; size_t total; };
 static void carve_du_bwd(char* base, int dtype, int Cs, int Cb, int B, int Hs, int Ws, DuBwdWs* o) {
     // Cs/Hs/Ws: the SMALL (low-resolution) side, Cb the big side's channels; the bias gradient sums run over whichever side

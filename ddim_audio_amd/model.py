@@ -189,6 +189,28 @@ def _dft_tables(n):
     return np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
 
 
+class ForkContext:
+    """Second stream + fork / join events of ``ddimx_unet_fwd_forked`` for ONE owner: either a model's eager calls or one
+    graph capture.  An event set is never shared between eager launches and a capture, nor between two captures (a HIP event
+    last recorded inside a capture must not be re-recorded eagerly), and it must outlive every graph whose capture recorded
+    it and die after that graph: so whoever captures owns its context and drops it after the graph (``DDIMStepper.close``).
+    The events are created here -- eagerly, by a first record on the current stream; torch creates the hipEvent lazily and
+    that must not happen inside a capture."""
+
+    def __init__(self, device, n_events, aux=None):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a ForkContext must be created before the capture that uses it")
+        self.device = device
+        self.aux = aux if aux is not None else torch.cuda.Stream(device=device)
+        self.events = [torch.cuda.Event() for _ in range(n_events)]
+        for e in self.events:
+            e.record()
+
+    def event_array(self):
+        import ctypes
+        return (ctypes.c_void_p * len(self.events))(*[e.cuda_event for e in self.events])
+
+
 class _UNetTrainFn(torch.autograd.Function):
     """Autograd node of the training-mode forward: ddimx_unet_fwd_train keeps a tape, backward = ddimx_unet_bwd.
     Gradients of all parameters land in ONE fresh fp32 buffer (views are handed to autograd), which is also the buffer a
@@ -304,6 +326,13 @@ class Model(_Node):
         self._dirty = True
         self._tables = {}
         self._workspace = None
+        self._temb_buf = None   # [n_timesteps, E] eval-mode BetaEmbedding table: allocated once, rebuilt in place on a repack
+        self._temb_table = None  # = _temb_buf while it is valid for the packed weights (eval mode), else None
+        self._eager_fork = None  # ForkContext of the eager (non-captured) forked forwards
+        # generation of the device buffers a captured graph holds raw pointers to (packed weights, embedding table, tables,
+        # workspaces): bumped whenever one of them is re-allocated; a capturer compares it before every replay
+        # (sampler.DDIMStepper) and re-captures instead of replaying pointers of an earlier generation
+        self._gen = 0
         # which parts of the eval forward run as two batch shards on two streams (ddimx_unet_fwd_forked): bit l = level l,
         # bit 16 = the FNet; 0 turns it off.  Default: everything -- measured: the gain needs the two shards to
         # run independently from the input conv to the output conv; forking only some levels (every join is a rendezvous)
@@ -323,11 +352,16 @@ class Model(_Node):
         self._dirty = True
 
     def _apply(self, fn, *a, **k):
+        # .to() / .type(): every derived device buffer is rebuilt on the next forward.  Dropping the references here frees
+        # nothing a live graph still points at: a capturer holds its own references (captured_refs) and sees the new
+        # generation before its next replay.
         self._dirty = True
-        self._fork_res = None
+        self._eager_fork = None
         self._tables = {}
         self._workspace = None
         self._packed = None
+        self._temb_buf = self._temb_table = None
+        self._gen = getattr(self, "_gen", 0) + 1
         return super()._apply(fn, *a, **k)
 
     def __del__(self):
@@ -396,6 +430,7 @@ class Model(_Node):
                 raise RuntimeError(f"parameter {name} must be a contiguous fp32 tensor on {device} (is {t.dtype} on {t.device})")
         if self._packed is None or self._packed.device != device:
             self._packed = torch.empty(int(lib.ddimx_packed_bytes(self._handle)), dtype=torch.uint8, device=device)
+            self._gen += 1
         import ctypes
         arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         _lib.check(lib.ddimx_pack_weights(self._handle, arr, len(tensors), _lib.ptr(self._packed), _lib.stream()))
@@ -417,7 +452,10 @@ class Model(_Node):
         tt = torch.arange(n, dtype=torch.int64, device=device)
         h1 = torch.empty(n, _EMB_CH, dtype=torch.float32, device=device)
         h2 = torch.empty_like(h1)
-        out = torch.empty(n, e, dtype=torch.float32, device=device)
+        out = self._temb_buf  # rebuilt IN PLACE: graphs captured against an earlier weight set keep a valid pointer
+        if out is None or out.device != device or tuple(out.shape) != (n, e):
+            out = self._temb_buf = torch.empty(n, e, dtype=torch.float32, device=device)
+            self._gen += 1
         w = [get(f"temb.weight.{i}.{k}") for i in range(3) for k in ("weight", "bias")]
         _lib.check(lib.ddimx_temb_fwd(_lib.ptr(get("temb.te")), _lib.ptr(tt), *[_lib.ptr(v) for v in w], _lib.ptr(h1), _lib.ptr(h2),
                                       _lib.ptr(out), n, _POS_CH, _EMB_CH, e, _lib.stream()))
@@ -430,6 +468,44 @@ class Model(_Node):
         with torch.cuda.device(device):
             self._ensure_packed(lib, device)
             self._ensure_tables(t_len, device)
+
+    def reserve(self, device, batch, t_len, slot=0):
+        """Allocate (or grow) workspace ``slot`` for a [batch, C, t_len, F] forward on the CURRENT stream.  The sampler calls
+        this for every shard from its launch stream before it forks, so that no workspace is ever allocated on a side stream
+        or inside a capture."""
+        lib = self._ensure_handle()
+        need = int(lib.ddimx_workspace_bytes(self._handle, batch, t_len))
+        if need <= 0:
+            raise RuntimeError("libddimx: bad workspace size for B=%d T=%d" % (batch, t_len))
+        if self._workspace is None:
+            self._workspace = {}
+        wsp = self._workspace.get(slot)
+        if wsp is None or wsp.numel() < need or wsp.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("workspace slot %d must be reserved before the capture (Model.reserve)" % slot)
+            with torch.cuda.device(device):
+                wsp = self._workspace[slot] = torch.empty(need, dtype=torch.uint8, device=device)
+            self._gen += 1
+        return wsp
+
+    def captured_refs(self):
+        """Every device buffer a graph captured over this model's forward holds a raw pointer to.  The capturer keeps the
+        list next to its graph, so the buffers live exactly as long as the graph, whatever happens to the model."""
+        refs = [self._packed, self._temb_buf] + list((self._workspace or {}).values())
+        for v in self._tables.values():
+            refs += list(v)
+        return [r for r in refs if r is not None]
+
+    def new_fork_context(self, device):
+        """A ForkContext for ONE graph capture (owned by the capturer); shares the model's aux stream."""
+        ef = self._eager_context(device)
+        return ForkContext(device, len(ef.events), aux=ef.aux)
+
+    def _eager_context(self, device):
+        ef = self._eager_fork
+        if ef is None or ef.device != device:
+            ef = self._eager_fork = ForkContext(device, 2 * len(self.config.ch) + 4)  # one event per fork / join of a call
+        return ef
 
     def _ensure_packed_bwd(self, lib, device):
         """Backward-only weight packings (data-gradient conv layouts, transposed FNet matrices); follows _ensure_packed."""
@@ -476,48 +552,21 @@ class Model(_Node):
             dh = torch.from_numpy(np.stack([ch, sh], axis=1).reshape(2 * hid, hid)).to(device)  # rows 2k: cos_k, 2k+1: sin_k
             ds = torch.from_numpy(np.concatenate([cs, -ss], axis=1)).contiguous().to(device)      # [S][2S] = [cos | -sin]
             self._tables = {key: (pe, dh, ds)}  # keep only the latest T
+            self._gen += 1
         return self._tables[key]
 
     # -- forward -------------------------------------------------------------------------------------
-    def forward_slot(self, input, t, slot):
+    def forward_slot(self, input, t, slot, out=None):
         """``forward`` over workspace ``slot``: concurrent calls on different HIP streams (the sampler's batch shards) must
         not share scratch memory.  Inference only; the in-library fork is off (the caller already runs shards in parallel)."""
-        return self.forward(input, t, _slot=slot, _fork=False)
+        return self.forward(input, t, _slot=slot, _fork=False, _out=out)
 
-    def _fork_resources(self, device, capturing):
-        """Second stream + fork / join events for ``ddimx_unet_fwd_forked``.  An event set is never shared between eager
-        launches and a graph capture, nor between two captures (a HIP event last recorded inside a capture must not be
-        re-recorded eagerly: seen as a crash in a later synchronize): eager calls own one set, every capture takes a fresh
-        one from a small pool that eager calls keep filled (events are created by their first record, which must not happen
-        inside a capture).  Returns (aux stream, events) or None when a capture finds the pool empty (the caller then runs the
-        unforked forward: same result, bit for bit)."""
-        res = getattr(self, "_fork_res", None)
-        n_ev = 2 * len(self.config.ch) + 4  # one per fork / join of a call
-
-        def new_set():
-            evs = [torch.cuda.Event() for _ in range(n_ev)]
-            for e in evs:
-                e.record()  # torch creates the hipEvent lazily; the library re-records it
-            return evs
-
-        if res is None or res["device"] != device:
-            if capturing:
-                return None
-            res = self._fork_res = {"device": device, "aux": torch.cuda.Stream(device=device), "eager": new_set(), "pool": [], "used": []}
-        if not capturing:
-            while len(res["pool"]) < 2:
-                res["pool"].append(new_set())
-            return res["aux"], res["eager"]
-        if not res["pool"]:
-            return None
-        evs = res["pool"].pop()
-        res["used"].append(evs)  # stays alive with the graphs that reference it
-        return res["aux"], evs
-
-    def forward(self, input, t, _slot=0, _fork=True):
+    def forward(self, input, t, _slot=0, _fork=True, _ctx=None, _out=None):
         """input [B, C, T, F] fp32 on the GPU, t [B] int64 -> eps [B, C, T, F] fp32 (reference :237-294).
         eval mode or no_grad: ``ddimx_unet_fwd``.  train mode with grad enabled: ``ddimx_unet_fwd_train`` (dropout active,
-        tape kept) as an autograd node whose backward fills every parameter's gradient (``ddimx_unet_bwd``)."""
+        tape kept) as an autograd node whose backward fills every parameter's gradient (``ddimx_unet_bwd``).
+        Internal keywords (sampler): ``_slot`` workspace slot, ``_fork`` allow the two-shard forward, ``_ctx`` the capturer's
+        ForkContext (a capture without one runs the unforked forward: same result, bit for bit), ``_out`` preallocated eps."""
         from . import _lib
         if not input.is_cuda:
             raise RuntimeError("ddim_audio_amd.Model computes only through libddimx on a ROCm GPU; got a CPU tensor "
@@ -532,15 +581,7 @@ class Model(_Node):
         with torch.cuda.device(dev):
             self._ensure_packed(lib, dev)
             pe, dh, ds = self._ensure_tables(t_len, dev)
-            need = int(lib.ddimx_workspace_bytes(self._handle, b, t_len))
-            if need <= 0:
-                raise RuntimeError("libddimx: bad workspace size for B=%d T=%d" % (b, t_len))
-            if self._workspace is None:
-                self._workspace = {}
-            wsp = self._workspace.get(_slot)
-            if wsp is None or wsp.numel() < need or wsp.device != dev:
-                self._workspace.pop(_slot, None)
-                wsp = self._workspace[_slot] = torch.empty(need, dtype=torch.uint8, device=dev)
+            wsp = self.reserve(dev, b, t_len, _slot)
             x = input.contiguous()
             tt = t.to(device=dev, dtype=torch.int64).contiguous()
             if self.training and torch.is_grad_enabled():
@@ -554,20 +595,26 @@ class Model(_Node):
                     # a stale one from an eager step would make the capture stream hand its gradients to that other stream.
                     params = self._leaf_aliases = [p.detach().requires_grad_(True) for p in params]
                 return _UNetTrainFn.apply(self, x, tt, (pe, dh, ds), *params)
-            out = torch.empty_like(x)
+            if _out is not None:
+                if _out.shape != x.shape or _out.dtype != torch.float32 or not _out.is_contiguous() or _out.device != dev:
+                    raise RuntimeError("_out must be a contiguous fp32 tensor of the input's shape on its device")
+                out = _out
+            else:
+                out = torch.empty_like(x)
             tt_ptr = self._temb_table.data_ptr() if (not self.training and getattr(self, "_temb_table", None) is not None) else None
             tables = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr(), tt_ptr)
             import ctypes
             mask = self.fork_mask if (_fork and b >= 4) else 0
-            fr = self._fork_resources(dev, torch.cuda.is_current_stream_capturing()) if mask else None
-            if fr is not None:
+            fc = None
+            if mask:
+                # eager calls use the model's own event set; a capture uses the set of whoever captures (never shared)
+                fc = _ctx if torch.cuda.is_current_stream_capturing() else self._eager_context(dev)
+            if fc is not None:
                 # two batch shards on two streams (bit-identical results); everything is joined back into
                 # the current stream before the call returns
-                aux, evs = fr
                 _lib.check(lib.ddimx_unet_fwd_forked(self._handle, _lib.ptr(self._packed), ctypes.byref(tables), _lib.ptr(wsp),
                                                      wsp.numel(), _lib.ptr(x), _lib.ptr(tt), _lib.ptr(out), b, t_len, _lib.stream(),
-                                                     ctypes.c_void_p(aux.cuda_stream),
-                                                     (ctypes.c_void_p * len(evs))(*[e.cuda_event for e in evs]), len(evs), mask))
+                                                     ctypes.c_void_p(fc.aux.cuda_stream), fc.event_array(), len(fc.events), mask))
             else:
                 _lib.check(lib.ddimx_unet_fwd(self._handle, _lib.ptr(self._packed), ctypes.byref(tables),
                                               _lib.ptr(wsp), wsp.numel(), _lib.ptr(x), _lib.ptr(tt),

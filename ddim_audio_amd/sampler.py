@@ -43,9 +43,19 @@ class DDIMStepper:
     captured once into a hipGraph and replayed for every later step.  The batch is cut into ``branches``
     contiguous shards, each enqueued on its own stream between a fork and a join (parallel branches of the
     captured graph); results do not depend on the cut (see ``_default_branches``).
+
+    Ownership.  The captured graph holds raw pointers into the model's packed weights, embedding table,
+    DFT / positional tables and workspaces, into this object's ``xt`` / ``x0`` / ``eps`` / ``t`` / ``coef`` / ``counter``,
+    and its capture recorded the fork / join events of ``ForkContext``.  All of these are referenced from HERE for as long as
+    the graph exists (``_refs``, ``_ctx``), the graph is destroyed FIRST (``close``), and a replay is refused -- the step
+    falls back to eager launches and re-captures -- when the model has re-allocated any of those buffers since the capture
+    (``Model._gen``) or needs a repack (``Model._dirty``).  Nothing is allocated on a side stream or inside the capture:
+    workspaces of all shards are reserved and the eps buffer is allocated on the launch stream before the fork.
     """
 
     def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None, branches=None):
+        self.graph = None          # first attribute: close() / __del__ must find it whatever else failed
+        self._ctx = self._refs = None
         self.lib = _lib.load()
         self.model, self.xt = model, xt
         dev = xt.device
@@ -57,32 +67,45 @@ class DDIMStepper:
         self.noise_fn = noise_fn
         self.use_graph = (use_graph and noise_fn is None and os.environ.get("DDIMX_GRAPH", "1") != "0"
                           and not torch.cuda.is_current_stream_capturing())
-        self.graph = None
         self.done = 0
+        self.captures = 0
+        self._capture_pending = self.use_graph
+        self._gen = None
         from .dist import shard_bounds
+        self.native = hasattr(model, "forward_slot")  # ddim_audio_amd.Model; anything else is called as model(x, t)
         nb = branches if branches is not None else _default_branches(xt.size(0))
-        if not hasattr(model, "forward_slot"):
-            nb = 1  # a plain callable / foreign module: one branch, called as model(x, t)
+        if not self.native:
+            nb = 1
         nb = max(1, min(nb, xt.size(0)))
         self.bounds = [shard_bounds(xt.size(0), r, nb) for r in range(nb)]
         self.side = [torch.cuda.Stream(device=dev) for _ in range(nb - 1)]
+        self.eps = torch.empty_like(xt) if self.native else None  # the forward writes here: no allocation per step
 
     def _branch(self, k, noise):
         lib, st = self.lib, _lib.stream()
         lo, hi = self.bounds[k]
         xt, t, x0 = self.xt[lo:hi], self.t[lo:hi], self.x0[lo:hi]
         _lib.check(lib.ddimx_step_begin(_lib.ptr(self.coef), _lib.ptr(self.counter), _lib.ptr(t), t.numel(), st))
-        et = self.model.forward_slot(xt, t, k) if len(self.bounds) > 1 else self.model(xt, t)
-        if et.dtype != torch.float32 or not et.is_contiguous():
-            et = et.float().contiguous()
+        if self.native:
+            et = self.model(xt, t, _slot=k, _fork=(len(self.bounds) == 1), _ctx=self._ctx, _out=self.eps[lo:hi])
+        else:
+            et = self.model(xt, t)
+            if et.dtype != torch.float32 or not et.is_contiguous():
+                et = et.float().contiguous()
         nz = None if noise is None else noise[lo:hi]
         _lib.check(lib.ddimx_ddim_update(_lib.ptr(xt), _lib.ptr(et), _lib.ptr(nz), _lib.ptr(x0), _lib.ptr(self.coef),
                                          _lib.ptr(self.counter), xt.numel(), st))
 
+    def _prepare(self):
+        """On the launch stream, before any fork: weight packing, tables, the workspaces of every shard."""
+        if self.native:
+            dev, t_len = self.xt.device, self.xt.size(2)
+            self.model.prepare(dev, t_len)
+            for k, (lo, hi) in enumerate(self.bounds):
+                self.model.reserve(dev, hi - lo, t_len, k)
+
     def _launch(self, noise):
         main = torch.cuda.current_stream(self.xt.device)
-        if self.side:
-            self.model.prepare(self.xt.device, self.xt.size(2))  # packing / tables on this stream, before the fork
         for s in self.side:                      # fork
             s.wait_stream(main)
         for k in range(1, len(self.bounds)):
@@ -97,18 +120,56 @@ class DDIMStepper:
         """Restart the coefficient table (benchmark loops longer than the schedule)."""
         self.counter.zero_()
 
+    def _stale(self):
+        m = self.model
+        return self.native and (m._dirty or m._gen != self._gen or m.training)
+
+    def _drop_graph(self):
+        """Destroy the graph, THEN release what its capture referenced (events, buffers)."""
+        g, self.graph = self.graph, None
+        if g is not None:
+            torch.cuda.synchronize(self.xt.device)  # no replay in flight when the executable graph goes away
+            del g
+        self._ctx = self._refs = None
+
+    def close(self):
+        self._drop_graph()
+
+    def __del__(self):
+        try:
+            g, self.graph = self.graph, None
+            del g                     # hipGraphExecDestroy first ...
+            self._ctx = self._refs = None  # ... then the events its capture recorded and the buffers it points at
+        except Exception:
+            pass
+
+    def _capture(self):
+        dev = self.xt.device
+        if self.native and len(self.bounds) == 1 and self.model.fork_mask and self.xt.size(0) >= 4:
+            self._ctx = self.model.new_fork_context(dev)  # created (and first recorded) eagerly, owned here
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._launch(None)
+        self.graph = g
+        self.captures += 1
+        if self.native:
+            self._refs = self.model.captured_refs()
+            self._gen = self.model._gen
+
     def step(self):
+        if self.graph is not None and self._stale():
+            self._drop_graph()
+            self._capture_pending = self.use_graph
         if self.graph is not None:
             self.graph.replay()
         else:
+            self._prepare()
             self._launch(self.noise_fn(self.xt) if self.noise_fn is not None else None)
-            if self.use_graph and self.done == 0:
-                # step 0 ran eagerly (it also sized the model's workspaces); capture one generic step
-                torch.cuda.synchronize(self.xt.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._launch(None)
-                self.graph = g
+            if self._capture_pending and not (self.native and self.model.training):
+                # this step ran eagerly (the first one also sized the model's workspaces); capture one generic step
+                self._capture_pending = False
+                self._capture()
         self.done += 1
 
 
@@ -137,11 +198,14 @@ def generalized_steps(x, seq, model, alpha, select_index, **kwargs):
         coef = ddim_coefficients(seq, alpha, eta)
         noise_fn = (lambda ref: torch.randn_like(ref)) if eta != 0.0 else None  # reference :42 draws it every step
         stepper = DDIMStepper(model, xt, coef, use_graph=(n_iter >= 4), noise_fn=noise_fn)
-        for index in range(n_iter):
-            stepper.step()
-            if _selected(select_index, index, n_iter):
-                x0_preds.append(stepper.x0.to("cpu"))
-                xs.append(xt.to("cpu"))
+        try:
+            for index in range(n_iter):
+                stepper.step()
+                if _selected(select_index, index, n_iter):
+                    x0_preds.append(stepper.x0.to("cpu"))
+                    xs.append(xt.to("cpu"))
+        finally:
+            stepper.close()  # graph first, then the events / buffers it referenced
     return xs, x0_preds
 
 

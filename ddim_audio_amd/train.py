@@ -117,7 +117,8 @@ class GraphedTrainStep:
 
     def __init__(self, model, state, alphas, warmup=2):
         self.model, self.state, self.alphas = model, state, alphas
-        self.warmup, self.calls, self.graph = max(1, int(warmup)), 0, None
+        self.graph = self._refs = None
+        self.warmup, self.calls = max(1, int(warmup)), 0
         self._side = torch.cuda.Stream()
         for o in state.optimizers.values():
             if not isinstance(o, optim.FusedAdam):
@@ -131,16 +132,22 @@ class GraphedTrainStep:
         return [(o, gi, g) for o in self.state.optimizers.values() for gi, g in enumerate(o.param_groups)]
 
     def _write_scalars(self):
-        """Values of the step about to run: every group's Adam scalars (step count + 1) and the dropout call counter + 1."""
+        """Values of the step about to run: every group's Adam scalars (step count + 1) and the dropout call counter + 1.
+        Staged through a RING of pinned host slots, each guarded by a HIP event recorded behind its upload: a slot is
+        overwritten only after the upload that last read it has executed.  (One pinned buffer re-used every call would let
+        step k's asynchronous upload carry step k+1's values -- the host runs ahead of a ~50 ms replay)"""
         vals = []
         for o, gi, g in self._groups():
             ps = [p for p in g["params"] if p.grad is not None or p in o.state]
             step = (o.state[ps[0]]["step"] if ps and o.state[ps[0]] else 0) + 1
             vals += list(optim.adam_step_scalars(g, step)) + [0.0]
-        self._h_dyn.copy_(torch.tensor(vals, dtype=torch.float32))
-        self._h_ctr[0] = int(getattr(self.model, "_dropout_calls", 0)) + 1
-        self._d_dyn.copy_(self._h_dyn, non_blocking=True)
-        self._d_ctr.copy_(self._h_ctr, non_blocking=True)
+        k = self._slot = (self._slot + 1) % len(self._h_dyn)
+        self._h_ev[k].synchronize()  # the upload that used this slot _RING calls ago (no-op when never recorded)
+        self._h_dyn[k].copy_(torch.tensor(vals, dtype=torch.float32))
+        self._h_ctr[k][0] = int(getattr(self.model, "_dropout_calls", 0)) + 1
+        self._d_dyn.copy_(self._h_dyn[k], non_blocking=True)
+        self._d_ctr.copy_(self._h_ctr[k], non_blocking=True)
+        self._h_ev[k].record()
 
     def _advance_host_state(self):
         """What the captured Python code did to host-side state during capture, once per replay."""
@@ -175,20 +182,18 @@ class GraphedTrainStep:
         self.model._dropout_calls = snap["calls"]
 
     # ---- the step ------------------------------------------------------------------------------------------------
+    _RING = 4
+
     def _capture(self, x):
         from . import _lib
         dev = x.device
         ng = len(self._groups())
-        self._h_dyn = torch.empty(4 * ng, dtype=torch.float32).pin_memory()
-        self._h_ctr = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._h_dyn = [torch.empty(4 * ng, dtype=torch.float32).pin_memory() for _ in range(self._RING)]
+        self._h_ctr = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(self._RING)]
+        self._h_ev = [torch.cuda.Event() for _ in range(self._RING)]
+        self._slot = -1
         self._d_dyn = torch.zeros(4 * ng, dtype=torch.float32, device=dev)
         self._d_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-        k = 0
-        for o in self.state.optimizers.values():
-            o.dyn = [self._d_dyn[4 * (k + gi):4 * (k + gi) + 3] for gi in range(len(o.param_groups))]
-            k += len(o.param_groups)
-        self.model._dropout_ctr_dev = self._d_ctr
-        _lib.check(_lib.load().ddimx_set_dropout_counter(self.model._handle, _lib.ptr(self._d_ctr)))
         self.x = torch.empty_like(x)
         self.e = torch.empty_like(x)
         self.t = torch.zeros(x.size(0), dtype=torch.int64, device=dev)
@@ -196,24 +201,47 @@ class GraphedTrainStep:
         snap = self._snapshot()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        # The device-scalar hooks exist only while the capture runs: the optimizers read (lr, bias corrections) from _d_dyn and
+        # the forward adds the device call counter to its dropout seed.  They are cleared again before anything else can run,
+        # so an eager train_step / optimizer.step() on the same model and state between replays takes the by-value path with
+        # the host-side counts that every replay keeps advancing (_advance_host_state) -- never a stale device scalar.
+        k = 0
+        for o in self.state.optimizers.values():
+            o.dyn = [self._d_dyn[4 * (k + gi):4 * (k + gi) + 3] for gi in range(len(o.param_groups))]
+            k += len(o.param_groups)
+        self.model._dropout_ctr_dev = self._d_ctr
+        _lib.check(_lib.load().ddimx_set_dropout_counter(self.model._handle, _lib.ptr(self._d_ctr)))
         self.model._alias_leaves = True
         try:
             with torch.cuda.graph(g, stream=self._side):
                 self.loss, self.norms = train_step(self.model, self.x, self.state, self.alphas, e=self.e, t=self.t, _assign_grads=True)
         finally:
             self.model._alias_leaves = False
-        self._restore(snap)  # capturing ran the host side of one step without executing it
-        self.graph = g
-
-    def close(self):
-        """Back to eager stepping: by-value Adam scalars and dropout seeds again."""
-        from . import _lib
-        for o in self.state.optimizers.values():
-            o.dyn = None
-        if getattr(self.model, "_dropout_ctr_dev", None) is not None:
+            for o in self.state.optimizers.values():
+                o.dyn = None
             self.model._dropout_ctr_dev = None
             _lib.check(_lib.load().ddimx_set_dropout_counter(self.model._handle, None))
-        self.graph = None
+        self._restore(snap)  # capturing ran the host side of one step without executing it
+        self.graph = g
+        # what the graph points at, kept next to it: the flat gradient buffer and the training workspace are re-used by eager
+        # steps, but must not be FREED (a batch-shape change re-allocates them) while this graph can still be replayed
+        self._refs = [getattr(self.model, n, None) for n in ("_flat_grad", "_train_ws", "_packed", "_packed_bwd")]
+
+    def close(self):
+        """Back to eager stepping.  The graph goes first, then the buffers it points at."""
+        g, self.graph = self.graph, None
+        if g is not None:
+            torch.cuda.synchronize()
+            del g
+        self._refs = None
+
+    def __del__(self):
+        try:
+            g, self.graph = self.graph, None
+            del g
+            self._refs = None
+        except Exception:
+            pass
 
     def __call__(self, x, e=None, t=None):
         n = x.size(0)

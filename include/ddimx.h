@@ -236,6 +236,20 @@ int ddimx_conv_out_fwd(int dtype, const void* a, const void* b, const float* w_p
 int ddimx_fnet_fwd(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
                    const void* x, float* out, int B, int T, void* stream);
 
+/* Transformer_Module alone in TRAINING mode (dropout after the projection and after every FNet FFN, tape kept) and its
+ * backward -- the `_bwd` twin of ddimx_fnet_fwd (models/diffusion.py:148-167; autograd through TransformerEmbedding :131-145,
+ * FNetEncoder modeling_fnet.py:138-279 and compute_out).  workspace / tape: the whole-network layouts for the same (B, T),
+ * ddimx_train_workspace_bytes / ddimx_train_tape_bytes; the launches are the ones ddimx_unet_fwd_train / ddimx_unet_bwd issue for
+ * the bottleneck.  x: tokens as for ddimx_fnet_fwd; out / d_out / d_x: fp32 [B*S][width] in the library's token order.
+ * ddimx_fnet_bwd WRITES every transformer.* gradient at its ddimx_grad_offset() of `grads` (ddimx_grad_floats() floats; the other
+ * entries are left untouched) and the gradient w.r.t. the tokens into d_x. */
+int ddimx_fnet_fwd_train(ddimx_handle h, const void* packed, const ddimx_tables* tables, void* workspace, long long workspace_bytes,
+                         void* tape, long long tape_bytes, const void* x, float* out, int B, int T, float dropout_p,
+                         unsigned long long seed, void* stream);
+int ddimx_fnet_bwd(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                   long long workspace_bytes, const void* tape, long long tape_bytes, const void* x, const float* d_out, float* d_x,
+                   float* grads, int B, int T, float dropout_p, unsigned long long seed, void* stream);
+
 /* ---- backward twins of the per-op forwards (autograd of the reference modules; gradients are WRITTEN, fp32, in the
  * parameter's own layout).  The whole-network ddimx_unet_bwd issues exactly these launches. -------------------------------
  * Downsample (models/diffusion.py:70-78): x [B][H][W][Cin] the forward input, dy [B][H/2][W/2][Cout]; w_dgrad = the SAME weight

@@ -563,3 +563,173 @@ def test_graphed_train_step_is_bit_identical_to_eager(default_opt):
             assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
     for k in sa.schedulers:
         assert sa.schedulers[k].state_dict()["last_epoch"] == sb.schedulers[k].state_dict()["last_epoch"]
+
+
+# ------------------------------------------------------------------------------- round 3: ownership / coverage gaps
+def test_staged_grad_sync_runs_on_rccl():
+    """The REAL ``make_grad_sync(...).staged`` on RCCL (it had never executed -- the two-rank test needs two
+    devices and the bucket test replaced it with a stand-in): a 1-rank ``nccl`` process group on the one GPU of the test
+    box, ``min_world=1`` so that the data-parallel backward takes the staged path -- the library records the three bucket
+    events, the side stream waits on them, the asynchronous RCCL all-reduces (ReduceOp.AVG) are issued under it and the main
+    stream waits for them.  With one rank the average is the identity: the gradients must equal the plain backward's bit for
+    bit, twice in a row (the events are re-recorded by the second call)."""
+    import torch.distributed as dist
+    from ddim_audio_amd import dist as ddist
+    cfg, m = _train_model("torch.cuda.BFloat16Tensor")
+    alphas = make_schedule(cfg.diffusion)[1].cuda()
+    shape = (4, 2, 256, 256)
+    x0, e = synth.gaussian("rccl.x0", shape).cuda(), synth.gaussian("rccl.e", shape).cuda()
+    t = torch.tensor([5, 994, 300, 650]).cuda()
+    losses.noise_estimation_loss(m, x0, t, e, alphas).backward()
+    plain = m._flat_grad.clone()
+    m.zero_grad(set_to_none=True)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        ddist.attach_grad_sync(m, bucket_mb=16, overlap=True, min_world=1)
+        assert m.grad_sync.active()
+        for _ in range(2):
+            losses.noise_estimation_loss(m, x0, t, e, alphas).backward()
+            torch.cuda.synchronize()
+            assert torch.equal(m._flat_grad, plain)
+            m.zero_grad(set_to_none=True)
+        # the un-overlapped form of the same collective
+        flat = plain.clone()
+        ddist.make_grad_sync(bucket_mb=16, overlap=False)(flat)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, plain)
+    finally:
+        m.grad_sync = None
+        if own:
+            dist.destroy_process_group()
+
+
+def test_generalized_steps_over_the_full_1000_entry_schedule():
+    """cfg2 / cfg5's step count (functions/denoising.py:10-52 with seq = range(1000)): the tiny configuration through all
+    1000 iterations of the captured step against the oracle's loop, fp32.  The trajectory is contractive towards the
+    model's fixed prediction, so the final x0 prediction is compared at the trajectory gate (10x the forward gate)."""
+    cfg = configs.tiny_config("torch.cuda.FloatTensor")
+    m = synth.fill_module(D.Model(cfg), 3).eval()
+    alphas = make_schedule(cfg.diffusion)[1]
+    seq = list(range(cfg.diffusion.num_diffusion_timesteps))
+    assert len(seq) == 1000
+    x = synth.gaussian("full1000.x", (2, cfg.model.channels, 32, cfg.model.f_size))
+    xs, x0s = D.generalized_steps(x.clone().cuda(), seq, m, alphas, [0, 499, -1], eta=0.0)
+    assert len(x0s) == 3 and len(xs) == 4
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ccfg = configs.tiny_config("torch.FloatTensor")
+    fn = lambda a, b: ref_cpu.model_forward(sd, ccfg, a, b)  # noqa: E731
+    with torch.no_grad():
+        rxs, rx0 = ref_cpu.generalized_steps(x.clone(), seq, fn, alphas, [0, 499, -1], eta=0.0)
+    for got, want, gate in ((x0s[0], rx0[0], 1e-4), (x0s[1], rx0[1], 1e-3), (x0s[2], rx0[2], 1e-3), (xs[-1], rxs[-1], 1e-3)):
+        assert torch.isfinite(got).all()
+        from conftest import rel_err
+        mx, rms = rel_err(got, want)
+        assert mx <= gate and rms <= gate / 5, (mx, rms)
+
+
+def test_stepper_owns_what_its_graph_references_and_recaptures_when_the_model_moves_on():
+    """DESIGN 9a (round 3).  (1) The graph's buffers and event set belong to the stepper: dropping every other reference to
+    the model's derived buffers (``_apply`` does exactly that) must not free what a live graph points at, and the next step
+    must notice the new generation, run eagerly and re-capture -- same trajectory, bit for bit, as an undisturbed run.
+    (2) A repack in between (``invalidate``) is picked up by the replayed graph: the embedding table is rebuilt IN PLACE.
+    (3) ``close`` destroys the graph before the events; a closed stepper keeps stepping eagerly."""
+    from ddim_audio_amd.sampler import DDIMStepper
+    from ddim_audio_amd import schedule
+    cfg, m = _eval_model("torch.cuda.BFloat16Tensor")
+    alphas = make_schedule(cfg.diffusion)[1]
+    seq = list(range(0, 1000, 100))
+    coef = schedule.ddim_coefficients(seq, alphas, 0.0)
+    x = synth.gaussian("own.x", (5, 2, 64, 256)).cuda()
+
+    def run(disturb):
+        xt = x.clone()
+        st = DDIMStepper(m, xt, coef, use_graph=True)
+        for i in range(len(seq)):
+            disturb(i, st)
+            st.step()
+        torch.cuda.synchronize()
+        out = (xt.clone(), st.x0.clone(), st.captures)
+        st.close()
+        assert st.graph is None and st._ctx is None and st._refs is None
+        return out
+
+    ref = run(lambda i, st: None)
+    assert ref[2] == 1
+
+    def move(i, st):
+        if i == 4:
+            assert st.graph is not None and st._ctx is not None and len(st._refs) >= 5
+            m.float()  # nn.Module._apply: the model drops its packed weights, tables, workspaces, embedding table
+            assert m._packed is None and m._workspace is None
+            junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]  # would land in freed blocks
+            del junk
+    got = run(move)
+    assert got[2] == 2, "the stepper must re-capture after the model re-allocated its buffers"
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+    def repack(i, st):
+        if i == 4:
+            tb = m._temb_buf.data_ptr()
+            m.invalidate()
+            st._tb = tb
+        if i == 5:
+            assert m._temb_buf.data_ptr() == st._tb and not m._dirty
+    got = run(repack)
+    assert got[2] == 1, "a repack must not need a new capture: every buffer is rebuilt in place"
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+    # (3) a closed stepper keeps working (eagerly, then captures again)
+    xt = x.clone()
+    st = DDIMStepper(m, xt, coef, use_graph=True)
+    for i in range(len(seq)):
+        if i == 3:
+            st.close()
+        st.step()
+    torch.cuda.synchronize()
+    assert torch.equal(xt, ref[0])
+    st.close()
+
+
+def test_graphed_train_step_with_device_resident_inputs_and_no_host_reads():
+    """the per-step scalars of GraphedTrainStep went through ONE pinned buffer uploaded asynchronously; with
+    device-resident ``t`` and nobody reading the loss between replays the host runs several replays ahead, and step k's
+    upload could carry step k+1's learning rate / bias corrections / dropout counter.  Now a ring of event-guarded pinned
+    slots: six replays without any host synchronisation must leave exactly the state of six eager steps."""
+    from ddim_audio_amd import train
+    cfg = configs.tiny_config("torch.cuda.FloatTensor")
+    cfg.optimization.optimizer.default.optimizer = "AdamW"
+    cfg.optimization.optimizer.default.warmup = 3     # the learning rate changes every step
+    alphas = make_schedule(cfg.diffusion)[1].cuda()
+    n = 8
+    xs = [synth.gaussian(f"ring.x{i}", (4, cfg.model.channels, 32, cfg.model.f_size)).cuda() for i in range(n)]
+    es = [synth.gaussian(f"ring.e{i}", (4, cfg.model.channels, 32, cfg.model.f_size)).cuda() for i in range(n)]
+    ts = [torch.tensor([7 + i, 992 - i, 300 + i, 699 - i], device="cuda") for i in range(n)]
+
+    def make():
+        torch.manual_seed(11)
+        m = synth.fill_module(D.Model(cfg), 5)
+        return m, train.TrainingState(cfg, m)
+
+    m1, s1 = make()
+    for i in range(n):
+        train.train_step(m1, xs[i], s1, alphas, e=es[i], t=ts[i])
+    m2, s2 = make()
+    step = train.GraphedTrainStep(m2, s2, alphas, warmup=2)
+    for i in range(n):
+        step(xs[i], e=es[i], t=ts[i])      # device-resident t, the returned loss is never read
+    torch.cuda.synchronize()
+    step.close()
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k
+    for k in s1.ema_helper.shadow:
+        assert torch.equal(s1.ema_helper.shadow[k], s2.ema_helper.shadow[k]), k
+    # the hooks of the capture are gone: an eager step on the same model / state continues the same trajectory
+    train.train_step(m1, xs[0], s1, alphas, e=es[0], t=ts[0])
+    train.train_step(m2, xs[0], s2, alphas, e=es[0], t=ts[0])
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k

@@ -203,6 +203,50 @@ def test_training_grad_sync_world2_gloo():
     assert all(a and b for _, a, b in res)
 
 
+def _staged_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+        from ddim_audio_amd import _lib, configs
+        import ddim_audio_amd as D
+        m = D.Model(configs.tiny_config("torch.FloatTensor"))
+        lib = m._ensure_handle()
+        rng = (ctypes.c_longlong * 6)()
+        _lib.check(lib.ddimx_grad_buckets(m._handle, rng))           # the real bucket ranges of the plan-ordered buffer
+        ranges = [(rng[2 * i], rng[2 * i + 1]) for i in range(3)]
+        total = int(lib.ddimx_grad_floats(m._handle))
+        base = torch.arange(total, dtype=torch.float32) % 1013
+        flat = base * (rank + 1)
+        sync = ddist.make_grad_sync(bucket_mb=1)
+        out = sync.staged(flat, ranges, None)                        # CPU rehearsal of the overlapped path: no events
+        want = base * (sum(range(1, world + 1)) / world)
+        tiles = sorted(ranges)
+        covers = tiles[0][0] == 0 and tiles[-1][1] == total and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))
+        q.put((rank, bool(torch.allclose(out, want)), covers, ranges))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_staged_grad_sync_world2_gloo_with_the_plans_bucket_ranges():
+    """The bucket plumbing of the overlapped data-parallel path (``make_grad_sync(...).staged``) over the REAL
+    ``ddimx_grad_buckets`` ranges of a model plan, two gloo ranks: every bucket is sliced, all-reduced and averaged, the three
+    ranges tile the flat buffer, both ranks end with the rank mean.  (The RCCL form of the same function runs on the GPU
+    box with a 1-rank group: tests/test_gpu_configs.py::test_staged_grad_sync_runs_on_rccl.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_staged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok and covers for _, ok, covers, _ in res), res
+    assert res[0][3] == res[1][3]
+
+
 def test_classify_group_and_antithetic_timesteps():
     """Parameter routing by top-level module name (runners/diffusion.py:71-87) and the antithetic draw (:141-142)."""
     from ddim_audio_amd import train
