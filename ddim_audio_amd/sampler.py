@@ -121,8 +121,18 @@ class DDIMStepper:
         self.counter.zero_()
 
     def _stale(self):
+        """Before a replay.  A pending repack (optimizer step, load_state_dict, EMA swap-in, invalidate()) is carried out
+        first, on the launch stream: packed weights and the embedding table are rebuilt IN PLACE, so the graph stays valid
+        and sees the new weights.  The graph is stale only if a buffer it points at was re-allocated since the capture
+        (``Model._gen``: .to() / .type(), another T, a larger batch in the same slot) or the model left eval mode."""
+        if not self.native:
+            return False
         m = self.model
-        return self.native and (m._dirty or m._gen != self._gen or m.training)
+        if m.training:
+            return True
+        if m._dirty:
+            self._prepare()
+        return m._gen != self._gen
 
     def _drop_graph(self):
         """Destroy the graph, THEN release what its capture referenced (events, buffers)."""
