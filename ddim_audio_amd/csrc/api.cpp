@@ -15,12 +15,13 @@
 #include "kernels.h"
 #include "train_kernels.h"
 #include "wgrad_mfma.h"
+#include "conv_fold.h"
 
 namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused;
+    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);
@@ -31,6 +32,8 @@ struct Knobs {
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
         two_tiles = geti("DDIMX_TWO_TILES", 0);
+        conv_stagger = geti("DDIMX_CONV_STAGGER", 0);
+        conv_fold = geti("DDIMX_CONV_FOLD", 1);  // A/B hook: 0 = the affine-input 3x3 convs keep the register-transform kernel
     }
 };
 static const Knobs& knobs() {
@@ -400,9 +403,35 @@ struct BatchPlanScope {
     ~BatchPlanScope() { g_batch_plan = false; }
 };
 // Plan of one conv launch: tile configuration and the persistent-workgroup split.
-struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; };
+struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; bool fold; };
+// The folded-affine kernel (conv_fold.h) takes a 3x3 conv whose input transform is a plain per-channel affine (the block's second
+// conv in the inference walk) when a configuration exists for the width and the image is a whole number of its tiles.  The
+// choice depends on the sample's size only (never on the batch).
+static bool fold_eligible(const ConvCall& q, FoldGeom* fg) {
+    if (!knobs().conv_fold || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.xf != XF_AFFINE || q.act > 1 || q.skip ||
+        q.aux || q.bwd_mode || q.batch_plan || g_batch_plan)
+        return false;
+    if (fold_geometry(q.cin, fg) != hipSuccess) return false;
+    return q.Hin % fg->th == 0 && q.Win % fg->tw == 0;
+}
 static int conv_plan(const ConvCall& q, ConvPlan* p) {
     ConvGeom& g = p->g;
+    p->fold = false;
+    FoldGeom fg;
+    if (fold_eligible(q, &fg)) {
+        p->fold = true;
+        p->Hv = q.Hin; p->Wv = q.Win; p->var = 0;
+        g.th = fg.th; g.tw = fg.tw; g.nb = g.nout = q.cout; g.classes = 1; g.lds_bytes = fg.lds_bytes; g.nthreads = fg.nthreads;
+        p->tiles_x = q.Win / fg.tw;
+        p->tiles_y = q.Hin / fg.th;
+        const int tiles_s = p->tiles_x * p->tiles_y;
+        int wps = tiles_s < 128 ? tiles_s : 128;
+        if (tiles_s / 8 > wps) wps = tiles_s / 8;  // at most 8 tiles (one tile row at F = 256) per workgroup
+        if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
+        p->tiles_per_wg = cdiv(tiles_s, wps);
+        p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
+        return 0;
+    }
     if (q.mode == DOWN4 && ((q.Hin | q.Win) & 1)) return fail("downsample needs even H, W (got %d x %d)", q.Hin, q.Win);
     p->Hv = q.mode == DOWN4 ? q.Hin / 2 : q.Hin;
     p->Wv = q.mode == DOWN4 ? q.Win / 2 : q.Win;
@@ -449,6 +478,21 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     ConvPlan pl;
     CHK(conv_plan(q, &pl));
     const ConvGeom& g = pl.g;
+    if (pl.fold) {
+        FoldArgs f;
+        memset(&f, 0, sizeof(f));
+        f.in = q.in; f.w = q.w; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
+        f.in_scale = q.in_scale; f.in_shift = q.in_shift; f.gn = q.gn; f.out = q.out; f.stats = q.stats;
+        f.stats_groups_c = q.groups ? q.cout : 0; f.act = q.act; f.stamps = q.stamps; f.stagger = knobs().conv_stagger;
+        if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
+        if (!q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
+        f.B = q.B; f.H = q.Hin; f.W = q.Win;
+        f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
+        if (nparts) *nparts = f.wgs_per_sample;
+        if (Cs) *Cs = q.cout;
+        HIPCHK(fold_launch(q.cin, f, s));
+        return 0;
+    }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = q.in; a.w = q.w; a.bias = q.bias; a.chan_add = q.chan_add; a.chan_add_stride = q.chan_add_stride;
@@ -461,6 +505,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     if (q.groups && q.cout % kGroups) return fail("conv: group-format statistics need cout %% 8 == 0");
     a.B = q.B; a.Hin = q.Hin; a.Win = q.Win;
     a.stamps = q.stamps;
+    a.stagger = knobs().conv_stagger;
     a.Hv = pl.Hv; a.Wv = pl.Wv;
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
     a.tiles_per_wg = pl.tiles_per_wg; a.wgs_per_sample = pl.wgs_per_sample;
@@ -1733,7 +1778,9 @@ int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const floa
 int ddimx_debug_conv3x3_stamps(int dtype, int C, const void* x, const void* w, const float* chan_add, const float* in_scale,
                                 const float* in_shift, void* y, float* stats, unsigned long long* stamps, int B, int H, int W,
                                 void* stream) {
-    ConvCall k = {dtype, CONV3, C, C, x, w, nullptr, chan_add, C, in_scale, in_shift, XF_AFFINE_SILU, 1, nullptr, y, stats, B, H, W};
+    // DDIMX_STAMP_XF=1 (diagnostic runs): stamp the block's second conv (affine input) instead of its first
+    static const int xf = getenv("DDIMX_STAMP_XF") ? atoi(getenv("DDIMX_STAMP_XF")) : XF_AFFINE_SILU;
+    ConvCall k = {dtype, CONV3, C, C, x, w, nullptr, chan_add, C, in_scale, in_shift, xf, 1, nullptr, y, stats, B, H, W};
     k.stamps = stamps;
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }

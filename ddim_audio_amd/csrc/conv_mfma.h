@@ -68,6 +68,8 @@ struct ConvArgs {
     int tiles_per_wg;       // consecutive tiles (x-major) walked by one workgroup
     int wgs_per_sample;     // ceil(tiles_x*tiles_y / tiles_per_wg); grid.x = B * wgs_per_sample
     unsigned long long* stamps;  // diagnostic builds only (-DDDIMX_STAMP): [grid.x][16] per-phase cycle sums
+    int stagger;            // > 0: a workgroup that is not the first resident one of its CU (LDS base != 0) sleeps stagger x 1024
+                            // cycles before its prologue, so that the CU's workgroups do not run their phases in lock-step
 };
 
 template <typename T, int CIN_, int NOUT_, int NB_, int MODE_, int TH_, int TW_, int WM_, int WN_, int KC_, int TPC_, int OVL_ = 0, int BWD_ = 0>
@@ -180,10 +182,14 @@ template <> struct Mma<float> {
 
 // In-kernel phase stamps (diagnostic build libddimx_stamp.so only; the product library never executes one).
 #ifdef DDIMX_STAMP
-#define DDIMX_STAMP_DECL unsigned long long st_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, st_last = 0; { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); }
+// per wave: [0..11] cycle sums per phase of the tile loop (s_memtime), [12] s_memrealtime (100 MHz) at kernel entry, [13] at the
+// start of the tile loop (= end of the prologue), [14] at exit, [15] HW_ID | XCC_ID << 32 (which CU / SIMD / XCD ran the wave)
+#define DDIMX_STAMP_ENTRY unsigned long long st_rt0 = 0; { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0) :: "memory"); }
+#define DDIMX_STAMP_DECL unsigned long long st_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, st_last = 0, st_rt1 = 0; { asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_last) :: "memory"); }
 #define DDIMX_STAMP_AT(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define DDIMX_STAMP_FLUSH() do { if (a.stamps && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) a.stamps[((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 12 + k_] = st_acc[k_]; } } while (0)
+#define DDIMX_STAMP_FLUSH() do { if (a.stamps && (threadIdx.x & 63) == 0) { unsigned long long rt2_; unsigned hw_, xcc_; asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt2_), "=s"(hw_), "=s"(xcc_) :: "memory"); unsigned long long* d_ = a.stamps + ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 16; for (int k_ = 0; k_ < 12; ++k_) d_[k_] = st_acc[k_]; d_[12] = st_rt0; d_[13] = st_rt1; d_[14] = rt2_; d_[15] = (unsigned long long)hw_ | ((unsigned long long)xcc_ << 32); } } while (0)
 #else
+#define DDIMX_STAMP_ENTRY
 #define DDIMX_STAMP_DECL
 #define DDIMX_STAMP_AT(k)
 #define DDIMX_STAMP_FLUSH()
@@ -200,6 +206,15 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     char* const otile = C::SEPARATE_OUT ? halo + C::HALO_BYTES : halo;
     float* const gnscr = (float*)(smem + C::LDS_RAW - C::GN_BYTES);
 
+    DDIMX_STAMP_ENTRY
+    if (a.stagger > 0) {  // uniform
+        unsigned la;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
+        if (la & 0xffu) {  // LDS_BASE != 0: another workgroup of this CU was placed first
+#pragma unroll 1
+            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % C::WM, wn = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;
@@ -694,7 +709,7 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
         }
     }
 
-    DDIMX_STAMP_FLUSH();
+    DDIMX_STAMP_AT(10);
     // The weight ring runs two chunks ahead, so the last tile leaves two chunks of LDS-DMA in flight that nothing consumes.
     // They must have landed before LDS is reused below (`red` overlays the ring): the compiler's barrier only waits for
     // lgkmcnt (the DMA is inline asm, invisible to its waitcnt pass), and a DMA landing late -- seen when another kernel
@@ -740,6 +755,8 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
             }
         }
     }
+    DDIMX_STAMP_AT(11);
+    DDIMX_STAMP_FLUSH();
 }
 
 

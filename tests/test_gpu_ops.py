@@ -32,7 +32,7 @@ def test_resblock_golden(golden, dt, c, hw):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("c,hw,b", [(32, (40, 72), 3), (64, (24, 40), 2), (96, (17, 33), 2), (128, (16, 24), 2),
+@pytest.mark.parametrize("c,hw,b", [(32, (40, 72), 3), (32, (40, 96), 3), (64, (24, 40), 2), (96, (17, 33), 2), (128, (16, 24), 2),
                                     (192, (9, 20), 1), (256, (20, 9), 2)])
 def test_resblock_multi_tile(dt, c, hw, b):
     """Shapes that span several workgroup tiles with ragged edges, checked against the CPU oracle."""
@@ -243,3 +243,44 @@ def test_conv_out_fwd_vs_oracle(dt, c0, cout, hw, b):
     _lib.check(lib.ddimx_conv_out_fwd(dt, _lib.ptr(an), _lib.ptr(sn), _lib.ptr(wp), _lib.ptr(bg), _lib.ptr(eps), b, c0, cout, h, w,
                                       _lib.stream()))
     G.check_close(eps.cpu(), want, G.F32, f"conv_out {c0}->{cout} {hw}")
+
+
+# ---- the folded-affine 3x3 conv (csrc/conv_fold.h): GroupNorm of the input folded into the weights ---------------------------------
+@pytest.mark.parametrize("offset", [0.0, 4.0], ids=["centred", "mean4"])
+@pytest.mark.parametrize("hw", [(8, 32), (24, 96), (16, 256)])
+def test_folded_affine_conv_vs_fp32_reference(hw, offset):
+    """Residual_Block's second conv, conv1(GN1(h)) + bias then SiLU (models/diffusion.py:49-53), as the inference walk launches it
+    at C = 32: bf16 NHWC input, per-(sample, channel) affine, whole tiles -> conv3_fold_kernel (the affine lives in the
+    per-workgroup weights, the zero padding of the NORMALISED tensor in nine border-class addends).  Against fp32 torch on the same
+    bf16-rounded operands: output at the bf16 gate (interior tile, all four borders, one-tile image), statistics of the values as
+    stored to 1e-4.  `mean4`: an input whose mean is four standard deviations (the un-centred part must not amplify the rounding of
+    the scaled weights: U is taken from the rounded weights)."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    dt, c, b = G.BF16, 32, 2
+    h, w = hw
+    x = (synth.gaussian(f"fold.x{h}", (b, c, h, w)) + offset).bfloat16().float()
+    wt = (synth.gaussian("fold.w", (c, c, 3, 3)) / (9 * c) ** 0.5)
+    bias = synth.gaussian("fold.b", (c,)) * 0.3
+    scale = synth.gaussian("fold.s", (b, c)) * 0.3 + 1.0
+    scale[0, 5] = 0.0                                    # a dead GroupNorm weight: the channel is the constant `shift`
+    shift = synth.gaussian("fold.t", (b, c)) * 0.5 - offset * scale
+    dev = G.dev()
+    xn = G.to_nhwc(x, dt)
+    wp = G.pack_conv(wt, dt)
+    y = torch.empty_like(xn)
+    stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, c, b, h, w)), device=dev)
+    bias_d, scale_d, shift_d = bias.to(dev), scale.to(dev), shift.to(dev)  # (named: a temporary would be freed before the launch)
+    _lib.check(lib.ddimx_conv3x3_fwd(dt, c, _lib.ptr(xn), _lib.ptr(wp), _lib.ptr(bias_d), None, 0, _lib.ptr(scale_d),
+                                     _lib.ptr(shift_d), 1, 1, _lib.ptr(y), _lib.ptr(stats), b, h, w, _lib.stream()))
+    torch.cuda.synchronize()
+    got = G.from_nhwc(y, dt)
+    yn = x * scale[:, :, None, None] + shift[:, :, None, None]
+    want = F.silu(F.conv2d(yn, wt.bfloat16().float(), bias, padding=1))
+    G.check_close(got, want, dt, f"folded conv {hw} offset {offset}")
+    # statistics: per-workgroup (sum, sumsq) partials per channel of the values AS STORED
+    # (the buffer is sized for the largest partition; unused slabs stay zero: sum over samples and partials)
+    st = stats.cpu().view(-1, c, 2).double().sum(0)
+    gs = got.double()
+    assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)

@@ -1,5 +1,5 @@
 """A/B of conv launch knobs in ONE process is impossible (the knobs are read once per process), so this runs each setting in a
-child process, three rounds interleaved, and prints the median: conv_ab.py LEVEL B XF "VAR:WPS" "VAR:WPS" ..."""
+child process, three rounds interleaved, and prints the median: conv_ab.py LEVEL B XF "VAR:WPS[:STAGGER]" "VAR:WPS[:STAGGER]" ..."""
 import os, subprocess, sys, statistics
 lvl, B, xf = sys.argv[1:4]
 settings = sys.argv[4:]
@@ -7,8 +7,9 @@ res = {s: [] for s in settings}
 here = os.path.dirname(os.path.abspath(__file__))
 for rnd in range(3):
     for s in settings:
-        var, wps = s.split(":")
+        var, wps, *rest = s.split(":")
         env = dict(os.environ)
+        if rest and rest[0] != "-": env["DDIMX_CONV_STAGGER"] = rest[0]
         if var != "-": env["DDIMX_CONV_VAR"] = var
         if wps != "-": env["DDIMX_CONV_WPS"] = wps
         out = subprocess.run([sys.executable, os.path.join(here, "conv_time.py"), lvl, B, xf], env=env, capture_output=True, text=True).stdout

@@ -11,6 +11,7 @@ from ddim_audio_amd import _lib  # noqa: E402
 lvl = int(sys.argv[1])
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+xf = int(os.environ.get("DDIMX_ONE_XF", "2"))  # 2: the block's first conv (affine + SiLU input, + temb); 1: its second (affine input, + bias)
 lib = _lib.load()
 dt, tdt = _lib.DDIMX_BF16, torch.bfloat16
 dev = torch.device("cuda", 0)
@@ -23,8 +24,13 @@ temb = torch.randn(B, C, device=dev) * 0.1
 scale = torch.rand(B, C, device=dev) + 0.5
 shift = torch.randn(B, C, device=dev) * 0.1
 stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)), device=dev)
+bias = torch.randn(C, device=dev) * 0.1
 for _ in range(reps):
-    _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale), _lib.ptr(shift), 2, 1,
-                                     _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+    if xf == 2:
+        _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale), _lib.ptr(shift), 2, 1,
+                                         _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+    else:
+        _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), None, 0, _lib.ptr(scale), _lib.ptr(shift), xf, 1,
+                                         _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
 torch.cuda.synchronize()
 print("done", float(y.float().abs().mean()))

@@ -23,18 +23,48 @@ temb = torch.randn(B, C, device=dev) * 0.1
 scale = torch.rand(B, C, device=dev) + 0.5
 shift = torch.randn(B, C, device=dev) * 0.1
 stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)), device=dev)
-stamps = torch.zeros(12 * (1 << 16), dtype=torch.int64, device=dev)
+stamps = torch.zeros(16 * (1 << 16), dtype=torch.int64, device=dev)
 for _ in range(3):
     stamps.zero_()
     _lib.check(lib.ddimx_debug_conv3x3_stamps(dt, C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(temb), _lib.ptr(scale), _lib.ptr(shift),
                                               _lib.ptr(y), _lib.ptr(stats), _lib.ptr(stamps), B, H, W, _lib.stream()))
 torch.cuda.synchronize()
-s = stamps.cpu().reshape(-1, 12)
-s = s[s.sum(1) > 0].double()
+raw = stamps.cpu().reshape(-1, 16)
+raw = raw[raw[:, 12] > 0]
+s = raw[:, :12].double()
 names = ["issue next halo", "MFMA loop", "barrier A", "epilogue 1 (acc->LDS)", "commit (separate out)", "barrier B", "epilogue 2 (stores+stats)",
-         "barrier C", "commit (overlay)", "barrier D", "-", "-"]
+         "barrier C", "commit (overlay)", "barrier D", "(after loop: drain)", "statistics tail"]
+if os.environ.get("DDIMX_STAMP_XF") == "1" and os.environ.get("DDIMX_CONV_FOLD", "1") != "0" and C == 32:
+    names = ["issue next halo DMA", "MFMA loop", "barrier A", "epilogue 1 (acc->LDS)", "-", "barrier B", "epilogue 2 (stores+stats)", "-",
+             "top: wait halo + barrier", "(loop overhead)", "(after loop)", "statistics tail"]
 tot = s.sum(1).mean()
 print(f"L{lvl} C={C} B={B}: {s.shape[0]} waves, mean stamped cycles per wave {tot:.0f}")
 for k, n in enumerate(names):
     if s[:, k].sum() > 0:
         print(f"  {n:28s} {s[:, k].mean():10.0f} cycles  {100 * s[:, k].mean() / tot:5.1f}%")
+# ---- timeline (s_memrealtime, 100 MHz): when do workgroups start, how long is the prologue, how full are the CU slots
+t0, t1, t2 = raw[:, 12].double(), raw[:, 13].double(), raw[:, 14].double()
+base = t0.min()
+us = lambda v: (v - base) / 100.0  # noqa: E731
+span = float(us(t2).max())
+print(f"kernel span (first entry -> last exit) {span:.1f} us")
+ent, ext = us(t0), us(t2)
+print(f"  wave entry times: median {ent.median():.1f}  90% {ent.quantile(0.9):.1f}  max {ent.max():.1f} us")
+print(f"  prologue (entry -> tile loop): mean {(t1 - t0).mean() / 100:.2f} us   min {(t1 - t0).min() / 100:.2f}  max {(t1 - t0).max() / 100:.2f}")
+print(f"  tile loop + tail (loop start -> exit): mean {(t2 - t1).mean() / 100:.2f} us; wave life mean {(t2 - t0).mean() / 100:.2f} us")
+clk = s.sum(1) / ((t2 - t1) / 100.0) / 1e3
+print(f"  in-kernel clock over the stamped part: median {clk.median():.2f} GHz")
+hw = raw[:, 15]
+cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (((hw >> 32) & 0xF) << 8)  # cu, sh, se, xcc
+busy = {}
+for c, a_, b_ in zip(cu.tolist(), ent.tolist(), ext.tolist()):
+    busy.setdefault(c, []).append((a_, b_))
+occ = []
+for c, iv in busy.items():
+    occ.append(sum(b_ - a_ for a_, b_ in iv) / span)
+occ = torch.tensor(occ)
+print(f"  {len(busy)} distinct CUs seen; resident waves per CU averaged over the span: mean {occ.mean():.2f} min {occ.min():.2f} max {occ.max():.2f}")
+hist = torch.histc(ent.float(), bins=10, min=0, max=span)
+print("  entries per tenth of the span:", [int(v) for v in hist.tolist()])
+hist = torch.histc(ext.float(), bins=10, min=0, max=span)
+print("  exits per tenth of the span:  ", [int(v) for v in hist.tolist()])

@@ -15,11 +15,11 @@ import sys
 csv.field_size_limit(1 << 30)
 
 
-def load_pass(d, want="conv_mfma_kernel"):
+def load_pass(d, want=("conv_mfma_kernel", "conv3_fold_kernel")):
     vals, dur = {}, {}
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if want not in r["Kernel_Name"]:
+            if not any(w in r["Kernel_Name"] for w in want):
                 continue
             did = int(r["Dispatch_Id"])
             vals.setdefault(r["Counter_Name"], {})[did] = float(r["Counter_Value"])
