@@ -71,6 +71,10 @@ _SIGS = {
     "ddimx_resblock_bwd": (c_int, [c_int, c_int] + [c_void_p] * 20 + [c_int, c_void_p] + [c_int] * 3 + [c_void_p]),
     "ddimx_conv3x3_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddimx_debug_set_stamps": (c_int, [c_void_p]),
+    "ddimx_pack_conv_frag": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddimx_conv3x3_wreg_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddimx_conv3x3_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "ddimx_debug_conv3x3_stamps": (c_int, [c_int, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "ddimx_resid_gn_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -16,12 +16,13 @@
 #include "train_kernels.h"
 #include "wgrad_mfma.h"
 #include "conv_fold.h"
+#include "conv_wreg.h"
 
 namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold;
+    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold, conv_wreg;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);
@@ -33,7 +34,8 @@ struct Knobs {
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
         two_tiles = geti("DDIMX_TWO_TILES", 0);
         conv_stagger = geti("DDIMX_CONV_STAGGER", 0);
-        conv_fold = geti("DDIMX_CONV_FOLD", 1);  // A/B hook: 0 = the affine-input 3x3 convs keep the register-transform kernel
+        conv_fold = geti("DDIMX_CONV_FOLD", 1);
+        conv_wreg = geti("DDIMX_CONV_WREG", 1);  // A/B hook: 0 = the 3x3 convs of C >= 64 keep the LDS weight ring (conv_mfma_kernel)  // A/B hook: 0 = the affine-input 3x3 convs keep the register-transform kernel
     }
 };
 static const Knobs& knobs() {
@@ -134,6 +136,7 @@ struct ddimx_ctx {
     int width;  // FNet token width
     int Fr;     // frequency bins at the bottleneck
     std::vector<ParamSpec> specs;
+    std::vector<size_t> frag_off;  // per spec: offset of a second, fragment-order copy of a 3x3 conv weight (conv_wreg.h), 0 = none
     size_t packed_bytes;
     // indices
     int te, tw[3], tb[3];
@@ -176,6 +179,14 @@ static RBW add_rb(ddimx_ctx* c, const std::string& p, int C, int k) {
     r.w0 = add_spec(c, p + "conv.0.weight", PK_CONV, C, C, k, k);
     r.w1 = add_spec(c, p + "conv.1.weight", PK_CONV, C, C, k, k);
     r.bias1 = add_spec(c, p + "conv.1.bias", PK_COPY, C);
+    WregGeom wg;
+    if (c->dtype == DT_BF16 && k == 3 && wreg_geometry(C, &wg) == hipSuccess) {  // second copy in MFMA fragment order
+        c->frag_off.resize(c->specs.size(), 0);
+        for (int i : {r.w0, r.w1}) {
+            c->frag_off[i] = c->packed_bytes;
+            c->packed_bytes += al256((size_t)9 * C * C * 2);
+        }
+    }
     return r;
 }
 
@@ -312,6 +323,18 @@ static size_t conv_stats_floats(int dtype, int mode, int cin, int cout, int B, i
         const size_t n = (size_t)B * cdiv(Wv, g.tw) * cdiv(Hv, g.th) * g.classes * g.nout * 2;
         if (n > mx) mx = n;
     }
+    if (mode == CONV3 && cin == cout && dtype == DT_BF16) {  // the specialised kernels partition a sample into their own tiles
+        FoldGeom fg;
+        WregGeom wg;
+        if (fold_geometry(cin, &fg) == hipSuccess) {
+            const size_t n = (size_t)B * cdiv(Wv, fg.tw) * cdiv(Hv, fg.th) * cout * 2;
+            if (n > mx) mx = n;
+        }
+        if (wreg_geometry(cin, &wg) == hipSuccess) {
+            const size_t n = (size_t)B * cdiv(Wv, wg.tw) * cdiv(Hv, wg.th) * cout * 2;
+            if (n > mx) mx = n;
+        }
+    }
     return mx;
 }
 
@@ -394,6 +417,7 @@ struct ConvCall {
     const void* aux = nullptr; const float* aux_scale = nullptr; const float* aux_shift = nullptr; int bwd_mode = 0;  // ConvArgs, same names
     GnIn gn = {};             // gn.stats set: the input's GroupNorm is finished inside the kernel (in_scale / in_shift unused)
     bool groups = false;      // statistics partials in group format (gn_fused.h)
+    const void* wf = nullptr; // the same weights in MFMA fragment order (conv_wreg.h), if the caller has them
 };
 
 // set for the duration of the whole-network training calls (see ConvCall::batch_plan)
@@ -403,7 +427,7 @@ struct BatchPlanScope {
     ~BatchPlanScope() { g_batch_plan = false; }
 };
 // Plan of one conv launch: tile configuration and the persistent-workgroup split.
-struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; bool fold; };
+struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; bool fold, wreg; };
 // The folded-affine kernel (conv_fold.h) takes a 3x3 conv whose input transform is a plain per-channel affine (the block's second
 // conv in the inference walk) when a configuration exists for the width and the image is a whole number of its tiles.  The
 // choice depends on the sample's size only (never on the batch).
@@ -414,9 +438,35 @@ static bool fold_eligible(const ConvCall& q, FoldGeom* fg) {
     if (fold_geometry(q.cin, fg) != hipSuccess) return false;
     return q.Hin % fg->th == 0 && q.Win % fg->tw == 0;
 }
+// The register-streamed-weights kernel (conv_wreg.h) takes the 3x3 convs of the inference walk from C = 64 up when the caller has
+// the fragment-order weights and the image is a whole number of its tiles (sample size only, never the batch).
+static bool wreg_eligible(const ConvCall& q, WregGeom* wg) {
+    if (!knobs().conv_wreg || !q.wf || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.act > 1 || q.skip || q.aux ||
+        q.bwd_mode || q.batch_plan || g_batch_plan)
+        return false;
+    if (q.xf != XF_NONE && q.xf != XF_AFFINE && q.xf != XF_AFFINE_SILU) return false;
+    if (wreg_geometry(q.cin, wg) != hipSuccess) return false;
+    return q.Hin % wg->th == 0 && q.Win % wg->tw == 0;
+}
 static int conv_plan(const ConvCall& q, ConvPlan* p) {
     ConvGeom& g = p->g;
     p->fold = false;
+    p->wreg = false;
+    WregGeom wgm;
+    if (wreg_eligible(q, &wgm)) {
+        p->wreg = true;
+        p->Hv = q.Hin; p->Wv = q.Win; p->var = 0;
+        g.th = wgm.th; g.tw = wgm.tw; g.nb = g.nout = q.cout; g.classes = 1; g.lds_bytes = wgm.lds_bytes; g.nthreads = wgm.nthreads;
+        p->tiles_x = q.Win / wgm.tw;
+        p->tiles_y = q.Hin / wgm.th;
+        const int tiles_s = p->tiles_x * p->tiles_y;
+        int wps = tiles_s < 128 ? tiles_s : 128;
+        if (tiles_s / 4 > wps) wps = tiles_s / 4;
+        if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
+        p->tiles_per_wg = cdiv(tiles_s, wps);
+        p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
+        return 0;
+    }
     FoldGeom fg;
     if (fold_eligible(q, &fg)) {
         p->fold = true;
@@ -478,6 +528,21 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     ConvPlan pl;
     CHK(conv_plan(q, &pl));
     const ConvGeom& g = pl.g;
+    if (pl.wreg) {
+        WregArgs f;
+        memset(&f, 0, sizeof(f));
+        f.in = q.in; f.wf = q.wf; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
+        f.in_scale = q.in_scale; f.in_shift = q.in_shift; f.gn = q.gn; f.out = q.out; f.stats = q.stats;
+        f.stats_groups_c = q.groups ? q.cout : 0; f.xf = q.xf; f.act = q.act; f.stamps = q.stamps;
+        if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
+        if (q.xf != XF_NONE && !q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
+        f.B = q.B; f.H = q.Hin; f.W = q.Win;
+        f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
+        if (nparts) *nparts = f.wgs_per_sample;
+        if (Cs) *Cs = q.cout;
+        HIPCHK(wreg_launch(q.cin, f, s));
+        return 0;
+    }
     if (pl.fold) {
         FoldArgs f;
         memset(&f, 0, sizeof(f));
@@ -519,6 +584,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
 struct RBPtrs {
     const float *g0, *b0, *g1, *b1, *g2, *bias1;
     const void *w0, *w1;
+    const void *w0f = nullptr, *w1f = nullptr;  // fragment-order copies (conv_wreg.h) or null
 };
 
 // What the training forward of one Residual_Block keeps for its backward: the two pre-activation tensors and the
@@ -569,11 +635,13 @@ static int run_resblock(int dtype, int C, const void* x, void* y, const float* t
         CHK(gn_of(stats, x_nparts, p.g0, p.b0, &g, &fu, 2, crounds, kGnFuseConvRounds, pl.g.nthreads));
         if (fu) k1.gn = g;
         k1.groups = true;
+        k1.wf = p.w0f;
         CHK(run_conv(k1, s, &np, &cs));
         CHK(gn_of(stats2, np, p.g1, p.b1, &g, &fu, 2, crounds, kGnFuseConvRounds, pl.g.nthreads));
         ConvCall k2 = {dtype, CONV3, C, C, h1, p.w1, p.bias1, nullptr, 0, scale, shift, XF_AFFINE, 1, nullptr, h2, stats, B, H, W};
         if (fu) k2.gn = g;
         k2.groups = true;
+        k2.wf = p.w1f;
         CHK(run_conv(k2, s, &np, &cs));
         const int rparts = resid_nparts(dtype, H * W, C);
         const int rrounds = (int)(((long long)rparts * B + kNumCUs * 8 - 1) / (kNumCUs * 8));
@@ -737,6 +805,10 @@ static RBPtrs rb_ptrs(const ddimx_ctx* c, const void* packed, const RBW& r) {
     p.g0 = pf(c, packed, r.g0); p.b0 = pf(c, packed, r.b0); p.g1 = pf(c, packed, r.g1); p.b1 = pf(c, packed, r.b1);
     p.g2 = pf(c, packed, r.g2); p.bias1 = pf(c, packed, r.bias1);
     p.w0 = pv(c, packed, r.w0); p.w1 = pv(c, packed, r.w1);
+    if ((size_t)r.w1 < c->frag_off.size() && c->frag_off[r.w0]) {
+        p.w0f = (const char*)packed + c->frag_off[r.w0];
+        p.w1f = (const char*)packed + c->frag_off[r.w1];
+    }
     return p;
 }
 
@@ -861,7 +933,11 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         if (!src) return fail("ddimx_pack_weights: parameter %d (%s) is null", i, p.name.c_str());
         switch (p.kind) {
             case PK_COPY: HIPCHK(push_copy(src, (float*)dst, p.numel)); break;
-            case PK_CONV: HIPCHK(pack_conv_launch(h->dtype, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
+            case PK_CONV:
+                HIPCHK(pack_conv_launch(h->dtype, src, dst, p.d0, p.d1, p.d2, p.d3, s));
+                if ((size_t)i < h->frag_off.size() && h->frag_off[i])
+                    HIPCHK(pack_conv_frag_launch(src, (char*)packed + h->frag_off[i], p.d0, p.d1, s));
+                break;
             case PK_CONV_F32: HIPCHK(pack_conv_launch(DT_F32, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
             case PK_CONVT: HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s)); break;
             case PK_BIAS2:
@@ -1773,6 +1849,24 @@ int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const floa
                       int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                       float* stats, int B, int H, int W, void* stream) {
     ConvCall k = {dtype, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
+    return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
+}
+static unsigned long long* g_debug_stamps = nullptr;
+int ddimx_debug_set_stamps(unsigned long long* stamps) { g_debug_stamps = stamps; return 0; }  // diagnostic builds: next conv launches stamp here
+int ddimx_pack_conv_frag(const float* w, void* dst, int O, int I, void* stream) {
+    if (!w || !dst) return fail("ddimx_pack_conv_frag: null argument");
+    HIPCHK(pack_conv_frag_launch(w, dst, O, I, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
+                           int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats,
+                           int B, int H, int W, void* stream) {
+    ConvCall k = {DT_BF16, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
+    k.wf = w_frag;
+    k.stamps = g_debug_stamps;
+    ConvPlan pl;
+    CHK(conv_plan(k, &pl));
+    if (!pl.wreg) return fail("ddimx_conv3x3_wreg_fwd: C=%d %dx%d xf=%d is not eligible for the register-streamed kernel", C, H, W, xf);
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
 int ddimx_debug_conv3x3_stamps(int dtype, int C, const void* x, const void* w, const float* chan_add, const float* in_scale,

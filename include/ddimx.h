@@ -198,6 +198,16 @@ int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const floa
                       int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                       float* stats, int B, int H, int W, void* stream);
 long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W);
+/* The same convolution through the register-streamed-weights kernel (csrc/conv_wreg.h; bf16, C in {64, 96, 128, 192, 256}, whole
+ * tiles): w_frag = the weights in MFMA fragment order, ddimx_pack_conv_frag(w [O][I][3][3] fp32 -> 9*O*I bf16).  This is what
+ * ddimx_unet_fwd launches for the Residual_Block convs (models/diffusion.py:46-53) of those widths; fails if the shape is not
+ * eligible (ddimx_conv3x3_fwd is the general entry). */
+int ddimx_pack_conv_frag(const float* w, void* dst, int O, int I, void* stream);
+/* Diagnostic builds (-DDDIMX_STAMP) only: ddimx_conv3x3_wreg_fwd writes its per-wave phase stamps here (null: off). */
+int ddimx_debug_set_stamps(unsigned long long* stamps);
+int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
+                           int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
+                           float* stats, int B, int H, int W, void* stream);
 /* Diagnostic only: as ddimx_conv3x3_fwd (xf = 2, act = 1); in a -DDDIMX_STAMP build of the library the kernel
  * also writes per-wave per-phase cycle sums to stamps[waves][12] (tools/conv_stamps.py). */
 int ddimx_debug_conv3x3_stamps(int dtype, int C, const void* x, const void* w, const float* chan_add,

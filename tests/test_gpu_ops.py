@@ -284,3 +284,50 @@ def test_folded_affine_conv_vs_fp32_reference(hw, offset):
     gs = got.double()
     assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+# ---- 3x3 conv with the weights streamed straight into registers (csrc/conv_wreg.h) -------------------------------------------------
+@pytest.mark.parametrize("xf", [2, 1, 0], ids=["affine_silu", "affine", "none"])
+@pytest.mark.parametrize("c,hw", [(64, (16, 64)), (96, (16, 32)), (128, (8, 64)), (192, (8, 32)), (256, (8, 16))])
+def test_wreg_conv_vs_fp32_reference(c, hw, xf):
+    """Both convs of Residual_Block (models/diffusion.py:46-53) as the inference walk launches them from C = 64 up: GroupNorm
+    affine (+ SiLU) on the input while the halo is staged, weights in MFMA fragment order read straight into registers, + bias /
+    + timestep embedding, SiLU, group statistics.  Against fp32 torch on the same bf16-rounded operands: multi-tile images with all
+    four borders, statistics of the values as stored."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    dt, b = G.BF16, 2
+    h, w = hw
+    dev = G.dev()
+    x = (synth.gaussian(f"wreg.x{c}", (b, c, h, w)) * 1.2 + 0.2).bfloat16().float()
+    wt = synth.gaussian(f"wreg.w{c}", (c, c, 3, 3)) / (9 * c) ** 0.5
+    bias = synth.gaussian(f"wreg.b{c}", (c,)) * 0.3
+    temb = synth.gaussian(f"wreg.t{c}", (b, c)) * 0.3
+    scale = synth.gaussian(f"wreg.s{c}", (b, c)) * 0.3 + 1.0
+    shift = synth.gaussian(f"wreg.h{c}", (b, c)) * 0.5
+    xn, wp = G.to_nhwc(x, dt), G.pack_conv(wt, dt)
+    wf = torch.empty(9 * c * c, dtype=torch.bfloat16, device=dev)
+    wt_d = wt.to(dev).contiguous()
+    _lib.check(lib.ddimx_pack_conv_frag(_lib.ptr(wt_d), _lib.ptr(wf), c, c, _lib.stream()))
+    y = torch.empty_like(xn)
+    stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, c, b, h, w)), device=dev)
+    bias_d, temb_d, scale_d, shift_d = bias.to(dev), temb.to(dev), scale.to(dev), shift.to(dev)
+    use_temb = xf == 2
+    _lib.check(lib.ddimx_conv3x3_wreg_fwd(c, _lib.ptr(xn), _lib.ptr(wp), _lib.ptr(wf), None if use_temb else _lib.ptr(bias_d),
+                                          _lib.ptr(temb_d) if use_temb else None, c, _lib.ptr(scale_d), _lib.ptr(shift_d), xf, 1,
+                                          _lib.ptr(y), _lib.ptr(stats), b, h, w, _lib.stream()))
+    torch.cuda.synchronize()
+    got = G.from_nhwc(y, dt)
+    yn = x
+    if xf:
+        yn = x * scale[:, :, None, None] + shift[:, :, None, None]
+        if xf == 2:
+            yn = F.silu(yn)
+    yn = yn.bfloat16().float()  # the kernel rounds the transformed input to bf16 before the MFMAs
+    add = temb[:, :, None, None] if use_temb else bias[None, :, None, None]
+    want = F.silu(F.conv2d(yn, wt.bfloat16().float(), None, padding=1) + add)
+    G.check_close(got, want, dt, f"wreg conv C={c} {hw} xf={xf}")
+    st = stats.cpu().view(-1, c, 2).double().sum(0)
+    gs = got.double()
+    assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
