@@ -456,7 +456,7 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
     if (wreg_eligible(q, &wgm)) {
         p->wreg = true;
         p->Hv = q.Hin; p->Wv = q.Win; p->var = 0;
-        g.th = wgm.th; g.tw = wgm.tw; g.nb = g.nout = q.cout; g.classes = 1; g.lds_bytes = wgm.lds_bytes; g.nthreads = wgm.nthreads;
+        g.th = wgm.th; g.tw = wgm.tw; g.nout = q.cout; g.nb = q.cout / wgm.nsplit; g.classes = 1; g.lds_bytes = wgm.lds_bytes; g.nthreads = wgm.nthreads;
         p->tiles_x = q.Win / wgm.tw;
         p->tiles_y = q.Hin / wgm.th;
         const int tiles_s = p->tiles_x * p->tiles_y;
@@ -538,7 +538,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         if (q.xf != XF_NONE && !q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
         f.B = q.B; f.H = q.Hin; f.W = q.Win;
         f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
-        if (nparts) *nparts = f.wgs_per_sample;
+        if (nparts) *nparts = f.wgs_per_sample * (q.groups ? g.nout / g.nb : 1);
         if (Cs) *Cs = q.cout;
         HIPCHK(wreg_launch(q.cin, f, s));
         return 0;

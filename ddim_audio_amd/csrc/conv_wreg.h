@@ -39,13 +39,16 @@ struct WregArgs {
     unsigned long long* stamps;  // diagnostic builds only (-DDDIMX_STAMP)
 };
 
-template <int C_, int TH_, int TW_, int WM_, int WN_, int D_>
+template <int C_, int TH_, int TW_, int WM_, int WN_, int D_, int NS_ = 1>
 struct WregCfg {
     static constexpr int C = C_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, D = D_;
+    static constexpr int NS = NS_;      // output-channel splits: grid.y workgroups share a pixel tile (the latency-bound deep levels
+                                        // have too few pixels to fill 256 CUs otherwise; each stages the small halo for itself)
+    static constexpr int NB = C / NS;   // output channels of one workgroup
     static constexpr int ES = 2, EPB = 8;
     static constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
     static constexpr int P = TH * TW;
-    static constexpr int MT = P / (32 * WM), NT = C / (32 * WN);
+    static constexpr int MT = P / (32 * WM), NT = NB / (32 * WN);
     static constexpr int KG = C / 16, NSTEP = 9 * KG, NBLK = C / 32;
     static constexpr int IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
     static constexpr int PSTRIDE = C * ES + 16;
@@ -53,17 +56,17 @@ struct WregCfg {
     static constexpr int ROWRES = TW == 8 ? 128 : 0;  // (row stride mod 256 B) wanted when a 32-pixel block spans rows
     static constexpr int ROWSTRIDE = TW >= 32 ? ROWRAW : ROWRAW + ((ROWRES - ROWRAW % 256) + 256) % 256;
     static constexpr int HALO_BYTES = IH * ROWSTRIDE;
-    static constexpr int OSTRIDE = C * ES + 16;
+    static constexpr int OSTRIDE = NB * ES + 16;
     static constexpr int OUT_BYTES = P * OSTRIDE;
     static constexpr int HO_BYTES = HALO_BYTES > OUT_BYTES ? HALO_BYTES : OUT_BYTES;  // the output tile overlays the halo
-    static constexpr int ADD_BYTES = C * 4;
+    static constexpr int ADD_BYTES = NB * 4;
     static constexpr int GN_BYTES = NWAVES * kGroups * 2 * 4;
-    static constexpr int RED_BYTES = NWAVES * C * 2 * 4;
-    static constexpr int LDS_RAW = ADD_BYTES + HO_BYTES + GN_BYTES;
+    static constexpr int RED_BYTES = NWAVES * NB * 2 * 4;
+    static constexpr int LDS_RAW = ADD_BYTES + HO_BYTES + GN_BYTES + 256;  // + 256 B sink of the weight warm-up touches
     static constexpr int LDS_BYTES = LDS_RAW > RED_BYTES ? LDS_RAW : RED_BYTES;
     static constexpr int CPP = C / EPB, LPP = next_pow2(CPP);
     static constexpr int PPP = NTHREADS / LPP, HPT = (NPIX + PPP - 1) / PPP;
-    static constexpr int OPP = C / EPB, OLPP = next_pow2(OPP);
+    static constexpr int OPP = NB / EPB, OLPP = next_pow2(OPP);
     static constexpr int STEP = NTHREADS / OLPP, NPASS = (P + STEP - 1) / STEP;
     static constexpr int WG_PER_CU = (160 * 1024) / LDS_BYTES < 1 ? 1 : (160 * 1024) / LDS_BYTES;
     // waves per SIMD the LDS footprint allows (at most 3 asked of the register allocator: <= 168 registers per lane)
@@ -73,10 +76,11 @@ struct WregCfg {
     static_assert(P % (32 * WM) == 0 && MT >= 1, "pixel tile must split into 32-pixel MFMA blocks");
     static_assert(TW == 8 || TW == 16 || TW == 32, "TW");
     static_assert((PSTRIDE / 16) % 2 == 1, "pixel stride must be odd in 16-byte slots");
-    static_assert(D >= 2 && D <= NSTEP, "prefetch depth");
+    static_assert(D >= 2 && D <= NSTEP && NSTEP % D == 0, "prefetch depth (the register ring wraps into the next tile: D must divide the step count)");
     static_assert(NTHREADS % LPP == 0 && NTHREADS % OLPP == 0 && OLPP <= 64 && NTHREADS <= 1024, "thread maps");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(HPT <= 16, "halo pieces per thread (all of a tile's loads are kept in registers)");
+    static_assert(HPT <= 24, "halo pieces per thread (all of a tile's loads are kept in registers)");
+    static_assert(C % NS == 0 && NB % 32 == 0, "cout split");
 };
 
 template <class F>
@@ -87,7 +91,8 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     float* const addv = (float*)smem;
     char* const halo = smem + F::ADD_BYTES;
     char* const otile = halo;
-    float* const gnscr = (float*)(smem + F::LDS_RAW - F::GN_BYTES);
+    float* const gnscr = (float*)(smem + F::LDS_RAW - F::GN_BYTES - 256);
+    char* const sink = smem + F::LDS_RAW - 256;
 
     DDIMX_STAMP_ENTRY
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,16 +110,50 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     const int ntile_s = a.tiles_x * a.tiles_y;
     const int t_begin = wg * a.tiles_per_wg;
     const int t_end = (t_begin + a.tiles_per_wg < ntile_s) ? t_begin + a.tiles_per_wg : ntile_s;
+    const int cout0 = blockIdx.y * F::NB;
 
     // ---- weight fragments: step s of this wave's cout block = one coalesced 16-byte-per-lane load -------------------------
     // (buffer load: resource in SGPRs, ONE per-lane offset register, the step as scalar offset -- 64-bit per-step addresses would be
     // hoisted out of the tile loop by the compiler, two registers per step, and spill)
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(a.wf, (unsigned)(9 * C * C * ES));
-    const unsigned wlane = (unsigned)((wn * 64 + lane) * 16);
+    const unsigned wlane = (unsigned)(((cout0 / 32 + wn) * 64 + lane) * 16);
     auto wfrag = [&](int s) __attribute__((always_inline)) -> uint4 {
         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wlane, s * (F::NBLK * 1024), 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
+    // L2 warm-up: inside the step every conv's weights were last read one U-Net evaluation ago and have long left the XCD's L2
+    // (18 MB of deep-level weights per step); the fragment stream then misses at every step and runs at (miss latency / D) per step
+    // (14 -> 24 us per launch at C = 256).  So the launch first TOUCHES every 128-byte line of the weight tensor once per XCD, all
+    // misses in flight together, under the GroupNorm reduction and the halo staging: hardware deals workgroups round-robin over the
+    // 8 XCDs (observed, speed only -- a wrong guess only warms the wrong L2), so workgroup i takes slice i / 8 of the lines of "its"
+    // XCD, one dword per lane.  The touches are LDS-DMA into a 256-byte sink: no destination registers, nothing ever waits for
+    // them except, in order, the first fragment load.
+    {
+        u32x4_t wrs;
+        const uint64_t wp = (uint64_t)a.wf;
+        wrs[0] = __builtin_amdgcn_readfirstlane((unsigned)wp);
+        wrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32));
+        wrs[2] = (unsigned)(9 * C * C * ES);
+        wrs[3] = 0x00020000u;
+        const unsigned sink_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(sink));
+        constexpr unsigned NL = 9u * C * C * ES / 128u;
+        const unsigned nsl = (gridDim.x * gridDim.y + 7u) >> 3;
+        const unsigned slice = (blockIdx.y * gridDim.x + blockIdx.x) >> 3;
+#pragma unroll 1
+        for (unsigned k = 0; (k * F::NWAVES * nsl) * 64u < NL; ++k) {
+            const unsigned line = ((k * F::NWAVES + (unsigned)wave) * nsl + slice) * 64u + (unsigned)lane;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dword %1, %2, 0 offen lds\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(line < NL ? line * 128u : 0x80000000u), "s"(wrs), "s"(sink_lds)
+                : "memory");
+        }
+    }
     uint4 aw[F::D];
 #pragma unroll
     for (int d = 0; d < F::D; ++d) aw[d] = wfrag(d);
@@ -190,15 +229,15 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc((T*)a.out + (size_t)bs * a.H * a.W * C, out_bytes);
 
     // ---- prologue (as conv_mfma_kernel): addend, GroupNorm input, first halo -------------------------------------------------
-    constexpr int AIT = (C + F::NTHREADS - 1) / F::NTHREADS;
+    constexpr int AIT = (F::NB + F::NTHREADS - 1) / F::NTHREADS;
     float add_b[AIT], add_c[AIT];
     {
-        const float* pb = a.bias ? a.bias : (const float*)a.wf;
-        const float* pc = a.chan_add ? a.chan_add + (size_t)bs * a.chan_add_stride : (const float*)a.wf;
+        const float* pb = a.bias ? a.bias + cout0 : (const float*)a.wf;
+        const float* pc = a.chan_add ? a.chan_add + (size_t)bs * a.chan_add_stride + cout0 : (const float*)a.wf;
 #pragma unroll
         for (int k = 0; k < AIT; ++k) {
             const int i = tid + k * F::NTHREADS;
-            const int ic = i < C ? i : C - 1;
+            const int ic = i < F::NB ? i : F::NB - 1;
             add_b[k] = pb[ic];
             add_c[k] = pc[ic];
         }
@@ -220,7 +259,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
 #pragma unroll
     for (int k = 0; k < AIT; ++k) {
         const int i = tid + k * F::NTHREADS;
-        if (i < C) addv[i] = (a.bias ? add_b[k] : 0.f) + (a.chan_add ? add_c[k] : 0.f);
+        if (i < F::NB) addv[i] = (a.bias ? add_b[k] : 0.f) + (a.chan_add ? add_c[k] : 0.f);
     }
     if (gn_fused) {
         gn_in_reduce(a.gn, bs, tid, F::NTHREADS, gn_ld, gnscr);
@@ -306,7 +345,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
 
         // ---- epilogue 2: whole pixel rows leave with 16-byte stores; statistics of the values as stored --------------------------
         if (ovalid) {
-            const unsigned cbase = (unsigned)(oc * 16);
+            const unsigned cbase = (unsigned)(cout0 * ES + oc * 16);
 #pragma unroll
             for (int k = 0; k < F::NPASS; ++k) {
                 const int p = oslot + k * F::STEP;
@@ -354,23 +393,24 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
         if (lane < F::OLPP && ovalid) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                red[(wave * C + oc * EPB + 2 * j) * 2 + 0] = st_s[j].x;
-                red[(wave * C + oc * EPB + 2 * j) * 2 + 1] = st_q[j].x;
-                red[(wave * C + oc * EPB + 2 * j + 1) * 2 + 0] = st_s[j].y;
-                red[(wave * C + oc * EPB + 2 * j + 1) * 2 + 1] = st_q[j].y;
+                red[(wave * F::NB + oc * EPB + 2 * j) * 2 + 0] = st_s[j].x;
+                red[(wave * F::NB + oc * EPB + 2 * j) * 2 + 1] = st_q[j].x;
+                red[(wave * F::NB + oc * EPB + 2 * j + 1) * 2 + 0] = st_s[j].y;
+                red[(wave * F::NB + oc * EPB + 2 * j + 1) * 2 + 1] = st_q[j].y;
             }
         }
         __syncthreads();
         const int nparts = a.wgs_per_sample;
         if (a.stats_groups_c) {
             if (wave == 0)
-                gn_bins_store<F::NWAVES>(red, C * 2, C, 0, a.stats_groups_c, a.stats + ((size_t)bs * nparts + wg) * kGnSlab, lane);
+                gn_bins_store<F::NWAVES>(red, F::NB * 2, F::NB, cout0, a.stats_groups_c,
+                                         a.stats + (((size_t)bs * nparts + wg) * F::NS + blockIdx.y) * kGnSlab, lane);
         } else {
-            for (int i = tid; i < C * 2; i += F::NTHREADS) {
+            for (int i = tid; i < F::NB * 2; i += F::NTHREADS) {
                 float tt = 0.f;
 #pragma unroll
-                for (int w = 0; w < F::NWAVES; ++w) tt += red[w * C * 2 + i];
-                a.stats[((size_t)bs * nparts + wg) * C * 2 + i] = tt;
+                for (int w = 0; w < F::NWAVES; ++w) tt += red[w * F::NB * 2 + i];
+                a.stats[(((size_t)bs * nparts + wg) * C + cout0) * 2 + i] = tt;
             }
         }
     }
@@ -386,12 +426,12 @@ hipError_t launch_wreg_cfg(const WregArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv3_wreg_kernel<F>, dim3(a.wgs_per_sample * a.B), dim3(F::NTHREADS), F::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(conv3_wreg_kernel<F>, dim3(a.wgs_per_sample * a.B, F::NS), dim3(F::NTHREADS), F::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
 // conv_inst_bf16_wreg.hip
-struct WregGeom { int th, tw, lds_bytes, nthreads; };
+struct WregGeom { int th, tw, lds_bytes, nthreads, nsplit; };
 hipError_t wreg_geometry(int C, WregGeom* g);
 hipError_t wreg_launch(int C, const WregArgs& a, hipStream_t stream);
 // weights [O][I][3][3] fp32 -> bf16 fragment order [9 * I/16][O/32][64][8]  (kernels.hip)

@@ -288,7 +288,8 @@ def test_folded_affine_conv_vs_fp32_reference(hw, offset):
 
 # ---- 3x3 conv with the weights streamed straight into registers (csrc/conv_wreg.h) -------------------------------------------------
 @pytest.mark.parametrize("xf", [2, 1, 0], ids=["affine_silu", "affine", "none"])
-@pytest.mark.parametrize("c,hw", [(64, (16, 64)), (96, (16, 32)), (128, (8, 64)), (192, (8, 32)), (256, (8, 16))])
+@pytest.mark.parametrize("c,hw", [(64, (16, 64)), (96, (16, 32)), (128, (8, 64)), (192, (8, 32)), (256, (8, 16)),
+                                  (96, (1040, 32)), (64, (1048, 32))])  # (tall: two tiles per workgroup -- the weight ring wraps)
 def test_wreg_conv_vs_fp32_reference(c, hw, xf):
     """Both convs of Residual_Block (models/diffusion.py:46-53) as the inference walk launches them from C = 64 up: GroupNorm
     affine (+ SiLU) on the input while the halo is staged, weights in MFMA fragment order read straight into registers, + bias /
