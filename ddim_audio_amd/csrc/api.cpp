@@ -628,20 +628,22 @@ static int run_resblock(int dtype, int C, const void* x, void* y, const float* t
             return 0;
         };
         GnIn g; bool fu;
+        // (each conv is planned exactly as run_conv will plan it -- kernel family, block size -- BEFORE its GroupNorm input is
+        // decided: the finalize launch must reduce with the block size of the kernel that would otherwise do it in its prologue)
         ConvCall k1 = {dtype, CONV3, C, C, x, p.w0, nullptr, temb, temb_stride, scale, shift, XF_AFFINE_SILU, 1, nullptr, h1, stats2, B, H, W};
-        ConvPlan pl;
-        CHK(conv_plan(k1, &pl));
-        const int crounds = conv_rounds(pl, B);
-        CHK(gn_of(stats, x_nparts, p.g0, p.b0, &g, &fu, 2, crounds, kGnFuseConvRounds, pl.g.nthreads));
-        if (fu) k1.gn = g;
         k1.groups = true;
         k1.wf = p.w0f;
+        ConvPlan pl;
+        CHK(conv_plan(k1, &pl));
+        CHK(gn_of(stats, x_nparts, p.g0, p.b0, &g, &fu, 2, conv_rounds(pl, B), kGnFuseConvRounds, pl.g.nthreads));
+        if (fu) k1.gn = g;
         CHK(run_conv(k1, s, &np, &cs));
-        CHK(gn_of(stats2, np, p.g1, p.b1, &g, &fu, 2, crounds, kGnFuseConvRounds, pl.g.nthreads));
         ConvCall k2 = {dtype, CONV3, C, C, h1, p.w1, p.bias1, nullptr, 0, scale, shift, XF_AFFINE, 1, nullptr, h2, stats, B, H, W};
-        if (fu) k2.gn = g;
         k2.groups = true;
         k2.wf = p.w1f;
+        CHK(conv_plan(k2, &pl));
+        CHK(gn_of(stats2, np, p.g1, p.b1, &g, &fu, 2, conv_rounds(pl, B), kGnFuseConvRounds, pl.g.nthreads));
+        if (fu) k2.gn = g;
         CHK(run_conv(k2, s, &np, &cs));
         const int rparts = resid_nparts(dtype, H * W, C);
         const int rrounds = (int)(((long long)rparts * B + kNumCUs * 8 - 1) / (kNumCUs * 8));
