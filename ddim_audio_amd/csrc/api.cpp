@@ -180,7 +180,7 @@ static RBW add_rb(ddimx_ctx* c, const std::string& p, int C, int k) {
     r.w1 = add_spec(c, p + "conv.1.weight", PK_CONV, C, C, k, k);
     r.bias1 = add_spec(c, p + "conv.1.bias", PK_COPY, C);
     WregGeom wg;
-    if (c->dtype == DT_BF16 && k == 3 && wreg_geometry(C, &wg) == hipSuccess) {  // second copy in MFMA fragment order
+    if (c->dtype == DT_BF16 && k == 3 && wreg_geometry(CONV3, C, C, &wg) == hipSuccess) {  // second copy in MFMA fragment order
         c->frag_off.resize(c->specs.size(), 0);
         for (int i : {r.w0, r.w1}) {
             c->frag_off[i] = c->packed_bytes;
@@ -237,6 +237,14 @@ static int build_plan(ddimx_ctx* c) {
         int j = 0;
         if (l > 0) {
             c->down_w[l] = add_spec(c, base + "0.conv.weight", PK_CONV, f.ch[l], f.ch[l - 1], 4, 4);
+            {
+                WregGeom wg;
+                if (c->dtype == DT_BF16 && wreg_geometry(DOWN4, f.ch[l - 1], f.ch[l], &wg) == hipSuccess) {
+                    c->frag_off.resize(c->specs.size(), 0);
+                    c->frag_off[c->down_w[l]] = c->packed_bytes;
+                    c->packed_bytes += al256((size_t)16 * f.ch[l] * f.ch[l - 1] * 2);
+                }
+            }
             c->down_b[l] = add_spec(c, base + "0.conv.bias", PK_COPY, f.ch[l]);
             j = 1;
         }
@@ -330,7 +338,14 @@ static size_t conv_stats_floats(int dtype, int mode, int cin, int cout, int B, i
             const size_t n = (size_t)B * cdiv(Wv, fg.tw) * cdiv(Hv, fg.th) * cout * 2;
             if (n > mx) mx = n;
         }
-        if (wreg_geometry(cin, &wg) == hipSuccess) {
+        if (wreg_geometry(CONV3, cin, cout, &wg) == hipSuccess) {
+            const size_t n = (size_t)B * cdiv(Wv, wg.tw) * cdiv(Hv, wg.th) * cout * 2;
+            if (n > mx) mx = n;
+        }
+    }
+    if (mode == DOWN4 && dtype == DT_BF16) {
+        WregGeom wg;
+        if (wreg_geometry(DOWN4, cin, cout, &wg) == hipSuccess) {
             const size_t n = (size_t)B * cdiv(Wv, wg.tw) * cdiv(Hv, wg.th) * cout * 2;
             if (n > mx) mx = n;
         }
@@ -418,6 +433,7 @@ struct ConvCall {
     GnIn gn = {};             // gn.stats set: the input's GroupNorm is finished inside the kernel (in_scale / in_shift unused)
     bool groups = false;      // statistics partials in group format (gn_fused.h)
     const void* wf = nullptr; // the same weights in MFMA fragment order (conv_wreg.h), if the caller has them
+    bool force_fold = false;  // ddimx_conv3x3_fold_fwd: take the folded-affine kernel whatever the DDIMX_CONV_FOLD default
 };
 
 // set for the duration of the whole-network training calls (see ConvCall::batch_plan)
@@ -432,7 +448,7 @@ struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, w
 // conv in the inference walk) when a configuration exists for the width and the image is a whole number of its tiles.  The
 // choice depends on the sample's size only (never on the batch).
 static bool fold_eligible(const ConvCall& q, FoldGeom* fg) {
-    if (!knobs().conv_fold || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.xf != XF_AFFINE || q.act > 1 || q.skip ||
+    if (!(knobs().conv_fold || q.force_fold) || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.xf != XF_AFFINE || q.act > 1 || q.skip ||
         q.aux || q.bwd_mode || q.batch_plan || g_batch_plan)
         return false;
     if (fold_geometry(q.cin, fg) != hipSuccess) return false;
@@ -441,12 +457,13 @@ static bool fold_eligible(const ConvCall& q, FoldGeom* fg) {
 // The register-streamed-weights kernel (conv_wreg.h) takes the 3x3 convs of the inference walk from C = 64 up when the caller has
 // the fragment-order weights and the image is a whole number of its tiles (sample size only, never the batch).
 static bool wreg_eligible(const ConvCall& q, WregGeom* wg) {
-    if (!knobs().conv_wreg || !q.wf || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.act > 1 || q.skip || q.aux ||
+    if (!knobs().conv_wreg || !q.wf || q.dtype != DT_BF16 || (q.mode != CONV3 && q.mode != DOWN4) || q.act > 1 || q.skip || q.aux ||
         q.bwd_mode || q.batch_plan || g_batch_plan)
         return false;
     if (q.xf != XF_NONE && q.xf != XF_AFFINE && q.xf != XF_AFFINE_SILU) return false;
-    if (wreg_geometry(q.cin, wg) != hipSuccess) return false;
-    return q.Hin % wg->th == 0 && q.Win % wg->tw == 0;
+    if (wreg_geometry(q.mode, q.cin, q.cout, wg) != hipSuccess) return false;
+    const int sxy = q.mode == DOWN4 ? 2 : 1;
+    return q.Hin % (wg->th * sxy) == 0 && q.Win % (wg->tw * sxy) == 0;
 }
 static int conv_plan(const ConvCall& q, ConvPlan* p) {
     ConvGeom& g = p->g;
@@ -455,10 +472,11 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
     WregGeom wgm;
     if (wreg_eligible(q, &wgm)) {
         p->wreg = true;
-        p->Hv = q.Hin; p->Wv = q.Win; p->var = 0;
+        const int sxy = q.mode == DOWN4 ? 2 : 1;
+        p->Hv = q.Hin / sxy; p->Wv = q.Win / sxy; p->var = 0;
         g.th = wgm.th; g.tw = wgm.tw; g.nout = q.cout; g.nb = q.cout / wgm.nsplit; g.classes = 1; g.lds_bytes = wgm.lds_bytes; g.nthreads = wgm.nthreads;
-        p->tiles_x = q.Win / wgm.tw;
-        p->tiles_y = q.Hin / wgm.th;
+        p->tiles_x = p->Wv / wgm.tw;
+        p->tiles_y = p->Hv / wgm.th;
         const int tiles_s = p->tiles_x * p->tiles_y;
         int wps = tiles_s < 128 ? tiles_s : 128;
         if (tiles_s / 4 > wps) wps = tiles_s / 4;
@@ -540,7 +558,7 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
         if (nparts) *nparts = f.wgs_per_sample * (q.groups ? g.nout / g.nb : 1);
         if (Cs) *Cs = q.cout;
-        HIPCHK(wreg_launch(q.cin, f, s));
+        HIPCHK(wreg_launch(q.mode, q.cin, q.cout, f, s));
         return 0;
     }
     if (pl.fold) {
@@ -938,7 +956,7 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
             case PK_CONV:
                 HIPCHK(pack_conv_launch(h->dtype, src, dst, p.d0, p.d1, p.d2, p.d3, s));
                 if ((size_t)i < h->frag_off.size() && h->frag_off[i])
-                    HIPCHK(pack_conv_frag_launch(src, (char*)packed + h->frag_off[i], p.d0, p.d1, s));
+                    HIPCHK(pack_conv_frag_launch(src, (char*)packed + h->frag_off[i], p.d0, p.d1, p.d2 * p.d3, s));
                 break;
             case PK_CONV_F32: HIPCHK(pack_conv_launch(DT_F32, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
             case PK_CONVT: HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s)); break;
@@ -1055,6 +1073,8 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
                               pf(c, packed, c->down_b[l]), nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr,
                               at(w.xd[l], act_bytes(l), ln.b0), stats_of(ln, 0), ln.n, H * 2, W * 2};
                 d.groups = true;
+                if ((size_t)c->down_w[l] < c->frag_off.size() && c->frag_off[c->down_w[l]])
+                    d.wf = (const char*)packed + c->frag_off[c->down_w[l]];
                 return run_conv(d, ln.st, &np, &cs);
             }));
             cur = 0;
@@ -1853,12 +1873,35 @@ int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const floa
     ConvCall k = {dtype, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
+int ddimx_conv3x3_fold_fwd(int C, const void* x, const void* w, const float* bias, const float* chan_add, int chan_add_stride,
+                           const float* in_scale, const float* in_shift, int act, void* y, float* stats, int B, int H, int W, void* stream) {
+    ConvCall k = {DT_BF16, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, XF_AFFINE, act, nullptr, y, stats, B, H, W};
+    k.force_fold = true;
+    ConvPlan pl;
+    CHK(conv_plan(k, &pl));
+    if (!pl.fold) return fail("ddimx_conv3x3_fold_fwd: C=%d %dx%d is not eligible for the folded-affine kernel", C, H, W);
+    return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
+}
 static unsigned long long* g_debug_stamps = nullptr;
 int ddimx_debug_set_stamps(unsigned long long* stamps) { g_debug_stamps = stamps; return 0; }  // diagnostic builds: next conv launches stamp here
 int ddimx_pack_conv_frag(const float* w, void* dst, int O, int I, void* stream) {
     if (!w || !dst) return fail("ddimx_pack_conv_frag: null argument");
-    HIPCHK(pack_conv_frag_launch(w, dst, O, I, (hipStream_t)stream));
+    HIPCHK(pack_conv_frag_launch(w, dst, O, I, 9, (hipStream_t)stream));
     return 0;
+}
+int ddimx_pack_conv_frag_k(const float* w, void* dst, int O, int I, int KK, void* stream) {
+    if (!w || !dst) return fail("ddimx_pack_conv_frag_k: null argument");
+    HIPCHK(pack_conv_frag_launch(w, dst, O, I, KK, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_downsample_wreg_fwd(int Cin, int Cout, const void* x, const void* w_frag, const float* bias, void* y, float* stats, int B,
+                              int H, int W, void* stream) {
+    ConvCall d = {DT_BF16, DOWN4, Cin, Cout, x, w_frag, bias, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, y, stats, B, H, W};
+    d.wf = w_frag;
+    ConvPlan pl;
+    CHK(conv_plan(d, &pl));
+    if (!pl.wreg) return fail("ddimx_downsample_wreg_fwd: %d->%d %dx%d is not eligible for the register-streamed kernel", Cin, Cout, H, W);
+    return run_conv(d, (hipStream_t)stream, nullptr, nullptr);
 }
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats,
@@ -1878,6 +1921,7 @@ int ddimx_debug_conv3x3_stamps(int dtype, int C, const void* x, const void* w, c
     static const int xf = getenv("DDIMX_STAMP_XF") ? atoi(getenv("DDIMX_STAMP_XF")) : XF_AFFINE_SILU;
     ConvCall k = {dtype, CONV3, C, C, x, w, nullptr, chan_add, C, in_scale, in_shift, xf, 1, nullptr, y, stats, B, H, W};
     k.stamps = stamps;
+    k.force_fold = xf == XF_AFFINE && getenv("DDIMX_CONV_FOLD") == nullptr;
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
 long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W) {

@@ -34,27 +34,29 @@ struct WregArgs {
     float* stats;
     int stats_groups_c;
     int xf, act;            // XF_NONE / XF_AFFINE / XF_AFFINE_SILU; act 0 / 1 (SiLU)
-    int B, H, W;
-    int tiles_x, tiles_y, tiles_per_wg, wgs_per_sample;
+    int B, H, W;            // the INPUT image (Downsample: the output is H/2 x W/2)
+    int tiles_x, tiles_y, tiles_per_wg, wgs_per_sample;  // tiles of the OUTPUT image
     unsigned long long* stamps;  // diagnostic builds only (-DDDIMX_STAMP)
 };
 
-template <int C_, int TH_, int TW_, int WM_, int WN_, int D_, int NS_ = 1>
+template <int CIN_, int COUT_, int MODE_, int TH_, int TW_, int WM_, int WN_, int D_, int NS_ = 1>
 struct WregCfg {
-    static constexpr int C = C_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, D = D_;
+    static constexpr int CIN = CIN_, COUT = COUT_, MODE = MODE_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, D = D_;
+    static_assert(MODE == CONV3 || MODE == DOWN4, "3x3 stride 1 (Residual_Block) or 4x4 stride 2 (Downsample)");
+    static constexpr int NTAPS = MODE == DOWN4 ? 16 : 9, TAPW = MODE == DOWN4 ? 4 : 3, SXY = MODE == DOWN4 ? 2 : 1;
     static constexpr int NS = NS_;      // output-channel splits: grid.y workgroups share a pixel tile (the latency-bound deep levels
                                         // have too few pixels to fill 256 CUs otherwise; each stages the small halo for itself)
-    static constexpr int NB = C / NS;   // output channels of one workgroup
+    static constexpr int NB = COUT / NS;   // output channels of one workgroup
     static constexpr int ES = 2, EPB = 8;
     static constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
     static constexpr int P = TH * TW;
     static constexpr int MT = P / (32 * WM), NT = NB / (32 * WN);
-    static constexpr int KG = C / 16, NSTEP = 9 * KG, NBLK = C / 32;
-    static constexpr int IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
-    static constexpr int PSTRIDE = C * ES + 16;
+    static constexpr int KG = CIN / 16, NSTEP = NTAPS * KG, NBLK = COUT / 32;
+    static constexpr int IH = SXY * TH + 2, IW = SXY * TW + 2, NPIX = IH * IW;
+    static constexpr int PSTRIDE = CIN * ES + 16;
     static constexpr int ROWRAW = IW * PSTRIDE;
     static constexpr int ROWRES = TW == 8 ? 128 : 0;  // (row stride mod 256 B) wanted when a 32-pixel block spans rows
-    static constexpr int ROWSTRIDE = TW >= 32 ? ROWRAW : ROWRAW + ((ROWRES - ROWRAW % 256) + 256) % 256;
+    static constexpr int ROWSTRIDE = (TW >= 32 || SXY == 2) ? ROWRAW : ROWRAW + ((ROWRES - ROWRAW % 256) + 256) % 256;
     static constexpr int HALO_BYTES = IH * ROWSTRIDE;
     static constexpr int OSTRIDE = NB * ES + 16;
     static constexpr int OUT_BYTES = P * OSTRIDE;
@@ -64,7 +66,7 @@ struct WregCfg {
     static constexpr int RED_BYTES = NWAVES * NB * 2 * 4;
     static constexpr int LDS_RAW = ADD_BYTES + HO_BYTES + GN_BYTES + 256;  // + 256 B sink of the weight warm-up touches
     static constexpr int LDS_BYTES = LDS_RAW > RED_BYTES ? LDS_RAW : RED_BYTES;
-    static constexpr int CPP = C / EPB, LPP = next_pow2(CPP);
+    static constexpr int CPP = CIN / EPB, LPP = next_pow2(CPP);
     static constexpr int PPP = NTHREADS / LPP, HPT = (NPIX + PPP - 1) / PPP;
     static constexpr int OPP = NB / EPB, OLPP = next_pow2(OPP);
     static constexpr int STEP = NTHREADS / OLPP, NPASS = (P + STEP - 1) / STEP;
@@ -80,13 +82,13 @@ struct WregCfg {
     static_assert(NTHREADS % LPP == 0 && NTHREADS % OLPP == 0 && OLPP <= 64 && NTHREADS <= 1024, "thread maps");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(HPT <= 24, "halo pieces per thread (all of a tile's loads are kept in registers)");
-    static_assert(C % NS == 0 && NB % 32 == 0, "cout split");
+    static_assert(COUT % NS == 0 && NB % 32 == 0 && CIN % 16 == 0, "cout split");
 };
 
 template <class F>
 __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const WregArgs a) {
     typedef __bf16 T;
-    constexpr int C = F::C, ES = 2, EPB = 8, NP = 4, TW = F::TW;
+    constexpr int CIN = F::CIN, COUT = F::COUT, ES = 2, EPB = 8, NP = 4, TW = F::TW, SXY = F::SXY;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const addv = (float*)smem;
     char* const halo = smem + F::ADD_BYTES;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     // ---- weight fragments: step s of this wave's cout block = one coalesced 16-byte-per-lane load -------------------------
     // (buffer load: resource in SGPRs, ONE per-lane offset register, the step as scalar offset -- 64-bit per-step addresses would be
     // hoisted out of the tile loop by the compiler, two registers per step, and spill)
-    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(a.wf, (unsigned)(9 * C * C * ES));
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(a.wf, (unsigned)(F::NTAPS * CIN * COUT * ES));
     const unsigned wlane = (unsigned)(((cout0 / 32 + wn) * 64 + lane) * 16);
     auto wfrag = [&](int s) __attribute__((always_inline)) -> uint4 {
         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wlane, s * (F::NBLK * 1024), 0);
@@ -133,10 +135,10 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
         const uint64_t wp = (uint64_t)a.wf;
         wrs[0] = __builtin_amdgcn_readfirstlane((unsigned)wp);
         wrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32));
-        wrs[2] = (unsigned)(9 * C * C * ES);
+        wrs[2] = (unsigned)(F::NTAPS * CIN * COUT * ES);
         wrs[3] = 0x00020000u;
         const unsigned sink_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(sink));
-        constexpr unsigned NL = 9u * C * C * ES / 128u;
+        constexpr unsigned NL = (unsigned)F::NTAPS * CIN * COUT * ES / 128u;
         const unsigned nsl = (gridDim.x * gridDim.y + 7u) >> 3;
         const unsigned slice = (blockIdx.y * gridDim.x + blockIdx.x) >> 3;
 #pragma unroll 1
@@ -164,8 +166,8 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     f32x2_t sc[NP], sh[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
-    const unsigned in_bytes = (unsigned)((size_t)a.H * a.W * C * ES);
-    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc((const T*)a.in + (size_t)bs * a.H * a.W * C, in_bytes);
+    const unsigned in_bytes = (unsigned)((size_t)a.H * a.W * CIN * ES);  // a.H x a.W: the INPUT image
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc((const T*)a.in + (size_t)bs * a.H * a.W * CIN, in_bytes);
     auto piece_xf = [&](auto xf_tag, uint4 v, bool ok) __attribute__((always_inline)) -> uint4 {
         constexpr int XF = decltype(xf_tag)::value;
         if (XF != XF_NONE) {
@@ -185,14 +187,14 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     uint4 hreg[F::HPT];
     unsigned hok = 0;
     auto halo_issue = [&](int ty, int tx) __attribute__((always_inline)) {
-        const int hy0 = ty * F::TH - 1, hx0 = tx * TW - 1;
+        const int hy0 = ty * F::TH * SXY - 1, hx0 = tx * TW * SXY - 1;
         hok = 0;
 #pragma unroll
         for (int i = 0; i < F::HPT; ++i) {
             const int pix = i * F::PPP + hslot;
             const int gy = hy0 + pix / F::IW, gx = hx0 + pix % F::IW;
             const bool ok = hvalid && pix < F::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            hreg[i] = buf_load16(in_rsrc, ok ? (unsigned)(((gy * a.W + gx) * C + hc * EPB) * ES) : kOOB);
+            hreg[i] = buf_load16(in_rsrc, ok ? (unsigned)(((gy * a.W + gx) * CIN + hc * EPB) * ES) : kOOB);
             hok |= ok ? (1u << i) : 0u;
         }
         asm volatile("" ::: "memory");
@@ -218,15 +220,16 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
 #pragma unroll
     for (int m = 0; m < F::MT; ++m) {
         const int p = (wm * F::MT + m) * 32 + l31;
-        pixoff[m] = (p / TW) * F::ROWSTRIDE + (p % TW) * F::PSTRIDE + h * 16;
+        pixoff[m] = (p / TW) * SXY * F::ROWSTRIDE + (p % TW) * SXY * F::PSTRIDE + h * 16;
     }
     const int oc = tid % F::OLPP, oslot = tid / F::OLPP;
     const bool ovalid = oc < F::OPP;
     f32x2_t st_s[NP], st_q[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
-    const unsigned out_bytes = (unsigned)((size_t)a.H * a.W * C * ES);
-    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc((T*)a.out + (size_t)bs * a.H * a.W * C, out_bytes);
+    const int Ho = a.H / SXY, Wo = a.W / SXY;  // output image
+    const unsigned out_bytes = (unsigned)((size_t)Ho * Wo * COUT * ES);
+    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc((T*)a.out + (size_t)bs * Ho * Wo * COUT, out_bytes);
 
     // ---- prologue (as conv_mfma_kernel): addend, GroupNorm input, first halo -------------------------------------------------
     constexpr int AIT = (F::NB + F::NTHREADS - 1) / F::NTHREADS;
@@ -247,8 +250,8 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     if (gn_fused) gn_in_issue(a.gn, bs, tid, F::NTHREADS, gn_ld);
     int ty = t_begin / a.tiles_x, tx = t_begin % a.tiles_x;
     if (a.xf != XF_NONE && hvalid) {
-        const float* psc = gn_fused ? a.gn.gamma + hc * EPB : a.in_scale + (size_t)bs * C + hc * EPB;
-        const float* psh = gn_fused ? (a.gn.beta ? a.gn.beta : a.gn.gamma) + hc * EPB : a.in_shift + (size_t)bs * C + hc * EPB;
+        const float* psc = gn_fused ? a.gn.gamma + hc * EPB : a.in_scale + (size_t)bs * CIN + hc * EPB;
+        const float* psh = gn_fused ? (a.gn.beta ? a.gn.beta : a.gn.gamma) + hc * EPB : a.in_shift + (size_t)bs * CIN + hc * EPB;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             sc[j] = *(const f32x2_t*)(psc + 2 * j);
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
                 gam[2 * j] = sc[j].x; gam[2 * j + 1] = sc[j].y;
                 bet[2 * j] = a.gn.beta ? sh[j].x : 0.f; bet[2 * j + 1] = a.gn.beta ? sh[j].y : 0.f;
             }
-            gn_in_fold<EPB>(a.gn, gnscr, F::NWAVES, C, hc * EPB, gam, bet, fs, fh);
+            gn_in_fold<EPB>(a.gn, gnscr, F::NWAVES, CIN, hc * EPB, gam, bet, fs, fh);
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 sc[j].x = fs[2 * j]; sc[j].y = fs[2 * j + 1];
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
         for (int s = 0; s < F::NSTEP; ++s) {
             if (s + 1 < F::NSTEP) {
                 const int tap = (s + 1) / F::KG, kg = (s + 1) % F::KG;
-                const int hoff = (tap / 3) * F::ROWSTRIDE + (tap % 3) * F::PSTRIDE + kg * 32;
+                const int hoff = (tap / F::TAPW) * F::ROWSTRIDE + (tap % F::TAPW) * F::PSTRIDE + kg * 32;
 #pragma unroll
                 for (int m = 0; m < F::MT; ++m) bq[(s + 1) & 1][m] = *(const uint4*)(halo + pixoff[m] + hoff);
             }
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
                 if (F::P % F::STEP != 0 && p >= F::P) break;
                 const int vy = y0 + p / TW, vx = x0 + p % TW;
                 const uint4 v = *(const uint4*)(otile + p * F::OSTRIDE + oc * 16);
-                buf_store16(out_rsrc, (unsigned)((vy * a.W + vx) * C * ES) + cbase, v);
+                buf_store16(out_rsrc, (unsigned)((vy * Wo + vx) * COUT * ES) + cbase, v);
                 f32x2_t f[NP];
                 Pairs<T>::unpack(v, f);
 #pragma unroll
@@ -410,7 +413,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
                 float tt = 0.f;
 #pragma unroll
                 for (int w = 0; w < F::NWAVES; ++w) tt += red[w * F::NB * 2 + i];
-                a.stats[(((size_t)bs * nparts + wg) * C + cout0) * 2 + i] = tt;
+                a.stats[(((size_t)bs * nparts + wg) * COUT + cout0) * 2 + i] = tt;
             }
         }
     }
@@ -432,9 +435,9 @@ hipError_t launch_wreg_cfg(const WregArgs& a, hipStream_t stream) {
 
 // conv_inst_bf16_wreg.hip
 struct WregGeom { int th, tw, lds_bytes, nthreads, nsplit; };
-hipError_t wreg_geometry(int C, WregGeom* g);
-hipError_t wreg_launch(int C, const WregArgs& a, hipStream_t stream);
-// weights [O][I][3][3] fp32 -> bf16 fragment order [9 * I/16][O/32][64][8]  (kernels.hip)
-hipError_t pack_conv_frag_launch(const float* w, void* dst, int O, int I, hipStream_t s);
+hipError_t wreg_geometry(int mode, int cin, int cout, WregGeom* g);
+hipError_t wreg_launch(int mode, int cin, int cout, const WregArgs& a, hipStream_t stream);
+// weights [O][I][KH][KW] fp32 -> bf16 fragment order [KH*KW * I/16][O/32][64][8]  (kernels.hip)
+hipError_t pack_conv_frag_launch(const float* w, void* dst, int O, int I, int KK, hipStream_t s);
 
 }  // namespace ddimx

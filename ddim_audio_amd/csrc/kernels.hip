@@ -1235,25 +1235,25 @@ hipError_t pack_conv_launch(int dtype, const float* w, void* dst, int O, int I, 
     return hipGetLastError();
 }
 
-// 3x3 conv weight [O][I][3][3] fp32 -> bf16 in MFMA fragment order (conv_wreg.h):
+// conv weight [O][I][KH][KW] fp32 (KK = KH * KW taps, row-major) -> bf16 in MFMA fragment order (conv_wreg.h):
 //   dst[step = tap * (I/16) + kg][nb][lane = h * 32 + l31][j]  =  w[co = nb * 32 + l31][ci = kg * 16 + h * 8 + j][tap]
-__global__ void pack_conv_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int O, int I) {
+__global__ void pack_conv_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int O, int I, int KK) {
     const int KG = I / 16, NBLK = O / 32;
-    const long long n = (long long)9 * O * I;
+    const long long n = (long long)KK * O * I;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
         const long long blk = i >> 9;
         const int nb = (int)(blk % NBLK), st = (int)(blk / NBLK);
         const int tap = st / KG, kg = st % KG;
         const int co = nb * 32 + (lane & 31), ci = kg * 16 + (lane >> 5) * 8 + j;
-        dst[i] = (__bf16)w[((size_t)co * I + ci) * 9 + tap];
+        dst[i] = (__bf16)w[((size_t)co * I + ci) * KK + tap];
     }
 }
-hipError_t pack_conv_frag_launch(const float* w, void* dst, int O, int I, hipStream_t s) {
+hipError_t pack_conv_frag_launch(const float* w, void* dst, int O, int I, int KK, hipStream_t s) {
     if (O % 32 || I % 16) return hipErrorInvalidValue;
-    const long long n = (long long)9 * O * I;
+    const long long n = (long long)KK * O * I;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_conv_frag_kernel, dim3(blocks), dim3(256), 0, s, w, (__bf16*)dst, O, I);
+    hipLaunchKernelGGL(pack_conv_frag_kernel, dim3(blocks), dim3(256), 0, s, w, (__bf16*)dst, O, I, KK);
     return hipGetLastError();
 }
 

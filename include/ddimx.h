@@ -203,8 +203,20 @@ long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W);
  * ddimx_unet_fwd launches for the Residual_Block convs (models/diffusion.py:46-53) of those widths; fails if the shape is not
  * eligible (ddimx_conv3x3_fwd is the general entry). */
 int ddimx_pack_conv_frag(const float* w, void* dst, int O, int I, void* stream);
+/* conv1(GN1(h)) + bias (+ SiLU) of Residual_Block (models/diffusion.py:49-53) through the folded-affine kernel (csrc/conv_fold.h:
+ * the GroupNorm affine folded into per-workgroup weights, the halo by LDS-DMA; bf16, C = 32, whole 8x32 tiles).  An alternative
+ * to ddimx_conv3x3_fwd(xf = 1) kept for A/B (DDIMX_CONV_FOLD=1 puts it into the network walk); w as for ddimx_conv3x3_fwd. */
+int ddimx_conv3x3_fold_fwd(int C, const void* x, const void* w, const float* bias, const float* chan_add, int chan_add_stride,
+                           const float* in_scale, const float* in_shift, int act, void* y, float* stats, int B, int H, int W,
+                           void* stream);
 /* Diagnostic builds (-DDDIMX_STAMP) only: ddimx_conv3x3_wreg_fwd writes its per-wave phase stamps here (null: off). */
 int ddimx_debug_set_stamps(unsigned long long* stamps);
+/* The same for any tap count (KK = KH * KW; Downsample: 16), and Downsample.forward (models/diffusion.py:70-78) through the
+ * register-streamed kernel: x [B][H][W][Cin] bf16 -> y [B][H/2][W/2][Cout], w_frag = ddimx_pack_conv_frag_k(w [Cout][Cin][4][4], 16);
+ * stats: per-channel (sum, sumsq) partials of y (sized for one partial per 32 output pixels), nullable. */
+int ddimx_pack_conv_frag_k(const float* w, void* dst, int O, int I, int KK, void* stream);
+int ddimx_downsample_wreg_fwd(int Cin, int Cout, const void* x, const void* w_frag, const float* bias, void* y, float* stats, int B,
+                              int H, int W, void* stream);
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                            float* stats, int B, int H, int W, void* stream);

@@ -271,8 +271,8 @@ def test_folded_affine_conv_vs_fp32_reference(hw, offset):
     y = torch.empty_like(xn)
     stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, c, b, h, w)), device=dev)
     bias_d, scale_d, shift_d = bias.to(dev), scale.to(dev), shift.to(dev)  # (named: a temporary would be freed before the launch)
-    _lib.check(lib.ddimx_conv3x3_fwd(dt, c, _lib.ptr(xn), _lib.ptr(wp), _lib.ptr(bias_d), None, 0, _lib.ptr(scale_d),
-                                     _lib.ptr(shift_d), 1, 1, _lib.ptr(y), _lib.ptr(stats), b, h, w, _lib.stream()))
+    _lib.check(lib.ddimx_conv3x3_fold_fwd(c, _lib.ptr(xn), _lib.ptr(wp), _lib.ptr(bias_d), None, 0, _lib.ptr(scale_d),
+                                          _lib.ptr(shift_d), 1, _lib.ptr(y), _lib.ptr(stats), b, h, w, _lib.stream()))
     torch.cuda.synchronize()
     got = G.from_nhwc(y, dt)
     yn = x * scale[:, :, None, None] + shift[:, :, None, None]
@@ -329,6 +329,37 @@ def test_wreg_conv_vs_fp32_reference(c, hw, xf):
     want = F.silu(F.conv2d(yn, wt.bfloat16().float(), None, padding=1) + add)
     G.check_close(got, want, dt, f"wreg conv C={c} {hw} xf={xf}")
     st = stats.cpu().view(-1, c, 2).double().sum(0)
+    gs = got.double()
+    assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(32, 64, (32, 64)), (64, 96, (16, 64)), (96, 128, (16, 32)), (128, 192, (16, 32)), (192, 256, (8, 32))])
+def test_wreg_downsample_vs_fp32_reference(cin, cout, hw):
+    """Downsample = Conv2d(k4, s2, p1) + bias (models/diffusion.py:70-78) through the register-streamed-weights kernel, as the
+    inference walk launches it: against fp32 torch on the same bf16-rounded operands, plus the statistics of the stored values.
+    (ddimx_downsample_fwd with fragment-order weights handed over next to the LDS layout.)"""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    dt, b = G.BF16, 2
+    h, w = hw
+    dev = G.dev()
+    x = (synth.gaussian(f"wdn.x{cin}", (b, cin, h, w)) * 1.2 + 0.1).bfloat16().float()
+    wt = synth.gaussian(f"wdn.w{cin}", (cout, cin, 4, 4)) / (16 * cin) ** 0.5
+    bias = synth.gaussian(f"wdn.b{cin}", (cout,)) * 0.3
+    xn = G.to_nhwc(x, dt)
+    wt_d, bias_d = wt.to(dev).contiguous(), bias.to(dev)
+    wf = torch.empty(16 * cin * cout, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.ddimx_pack_conv_frag_k(_lib.ptr(wt_d), _lib.ptr(wf), cout, cin, 16, _lib.stream()))
+    y = torch.empty(b, h // 2, w // 2, cout, dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros(b * (h // 2) * (w // 2) * cout * 2 // 8 + 4096, device=dev)
+    _lib.check(lib.ddimx_downsample_wreg_fwd(cin, cout, _lib.ptr(xn), _lib.ptr(wf), _lib.ptr(bias_d), _lib.ptr(y), _lib.ptr(stats), b, h, w,
+                                             _lib.stream()))
+    torch.cuda.synchronize()
+    got = G.from_nhwc(y, dt)
+    want = F.conv2d(x, wt.bfloat16().float(), bias, stride=2, padding=1)
+    G.check_close(got, want, dt, f"wreg down {cin}->{cout} {hw}")
+    st = stats.cpu()[: (stats.numel() // (cout * 2)) * cout * 2].view(-1, cout, 2).double().sum(0)
     gs = got.double()
     assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
