@@ -256,6 +256,14 @@ static int build_plan(ddimx_ctx* c) {
         for (int r = 0; r < f.res[l]; ++r) c->up_rb[l].push_back(add_rb(c, base + std::to_string(r) + ".", f.ch[l], 3));
         if (l > 0) {
             c->up_w[l] = add_spec(c, base + std::to_string(f.res[l]) + ".conv.weight", PK_CONVT, f.ch[l], f.ch[l - 1], 4, 4);
+            {
+                WregGeom wg;
+                if (c->dtype == DT_BF16 && wreg_geometry(UP4, f.ch[l], 2 * f.ch[l - 1], &wg) == hipSuccess) {
+                    c->frag_off.resize(c->specs.size(), 0);
+                    c->frag_off[c->up_w[l]] = c->packed_bytes;
+                    c->packed_bytes += al256((size_t)2 * 6 * 2 * f.ch[l - 1] * f.ch[l] * 2);
+                }
+            }
             c->up_b[l] = add_spec(c, base + std::to_string(f.res[l]) + ".conv.bias", PK_BIAS2, f.ch[l - 1]);
         }
     }
@@ -343,10 +351,11 @@ static size_t conv_stats_floats(int dtype, int mode, int cin, int cout, int B, i
             if (n > mx) mx = n;
         }
     }
-    if (mode == DOWN4 && dtype == DT_BF16) {
+    if (mode != CONV3 && dtype == DT_BF16) {
         WregGeom wg;
-        if (wreg_geometry(DOWN4, cin, cout, &wg) == hipSuccess) {
-            const size_t n = (size_t)B * cdiv(Wv, wg.tw) * cdiv(Hv, wg.th) * cout * 2;
+        const int nout = mode == UP4 ? 2 * cout : cout, ncls = mode == UP4 ? 2 : 1;
+        if (wreg_geometry(mode, cin, nout, &wg) == hipSuccess) {
+            const size_t n = (size_t)B * cdiv(Wv, wg.tw) * cdiv(Hv, wg.th) * ncls * nout * 2;
             if (n > mx) mx = n;
         }
     }
@@ -457,11 +466,10 @@ static bool fold_eligible(const ConvCall& q, FoldGeom* fg) {
 // The register-streamed-weights kernel (conv_wreg.h) takes the 3x3 convs of the inference walk from C = 64 up when the caller has
 // the fragment-order weights and the image is a whole number of its tiles (sample size only, never the batch).
 static bool wreg_eligible(const ConvCall& q, WregGeom* wg) {
-    if (!knobs().conv_wreg || !q.wf || q.dtype != DT_BF16 || (q.mode != CONV3 && q.mode != DOWN4) || q.act > 1 || q.skip || q.aux ||
-        q.bwd_mode || q.batch_plan || g_batch_plan)
-        return false;
+    if (!knobs().conv_wreg || !q.wf || q.dtype != DT_BF16 || q.act > 1 || q.aux || q.bwd_mode || q.batch_plan || g_batch_plan) return false;
+    if (q.skip && q.mode != UP4) return false;
     if (q.xf != XF_NONE && q.xf != XF_AFFINE && q.xf != XF_AFFINE_SILU) return false;
-    if (wreg_geometry(q.mode, q.cin, q.cout, wg) != hipSuccess) return false;
+    if (wreg_geometry(q.mode, q.cin, q.mode == UP4 ? 2 * q.cout : q.cout, wg) != hipSuccess) return false;
     const int sxy = q.mode == DOWN4 ? 2 : 1;
     return q.Hin % (wg->th * sxy) == 0 && q.Win % (wg->tw * sxy) == 0;
 }
@@ -474,7 +482,8 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
         p->wreg = true;
         const int sxy = q.mode == DOWN4 ? 2 : 1;
         p->Hv = q.Hin / sxy; p->Wv = q.Win / sxy; p->var = 0;
-        g.th = wgm.th; g.tw = wgm.tw; g.nout = q.cout; g.nb = q.cout / wgm.nsplit; g.classes = 1; g.lds_bytes = wgm.lds_bytes; g.nthreads = wgm.nthreads;
+        g.th = wgm.th; g.tw = wgm.tw; g.nout = q.mode == UP4 ? 2 * q.cout : q.cout; g.nb = g.nout / wgm.nsplit; g.classes = q.mode == UP4 ? 2 : 1;
+        g.lds_bytes = wgm.lds_bytes; g.nthreads = wgm.nthreads;
         p->tiles_x = p->Wv / wgm.tw;
         p->tiles_y = p->Hv / wgm.th;
         const int tiles_s = p->tiles_x * p->tiles_y;
@@ -549,16 +558,16 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     if (pl.wreg) {
         WregArgs f;
         memset(&f, 0, sizeof(f));
-        f.in = q.in; f.wf = q.wf; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
+        f.in = q.in; f.wf = q.wf; f.skip = q.skip; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
         f.in_scale = q.in_scale; f.in_shift = q.in_shift; f.gn = q.gn; f.out = q.out; f.stats = q.stats;
         f.stats_groups_c = q.groups ? q.cout : 0; f.xf = q.xf; f.act = q.act; f.stamps = q.stamps;
         if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
         if (q.xf != XF_NONE && !q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
         f.B = q.B; f.H = q.Hin; f.W = q.Win;
         f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
-        if (nparts) *nparts = f.wgs_per_sample * (q.groups ? g.nout / g.nb : 1);
-        if (Cs) *Cs = q.cout;
-        HIPCHK(wreg_launch(q.mode, q.cin, q.cout, f, s));
+        if (nparts) *nparts = f.wgs_per_sample * g.classes * (q.groups ? g.nout / g.nb : 1);
+        if (Cs) *Cs = g.nout;
+        HIPCHK(wreg_launch(q.mode, q.cin, g.nout, f, s));
         return 0;
     }
     if (pl.fold) {
@@ -959,7 +968,15 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
                     HIPCHK(pack_conv_frag_launch(src, (char*)packed + h->frag_off[i], p.d0, p.d1, p.d2 * p.d3, s));
                 break;
             case PK_CONV_F32: HIPCHK(pack_conv_launch(DT_F32, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
-            case PK_CONVT: HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s)); break;
+            case PK_CONVT:
+                HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s));
+                if ((size_t)i < h->frag_off.size() && h->frag_off[i]) {  // both row-parity classes, from the sub-pixel form just packed
+                    const size_t cls_bytes = (size_t)6 * 2 * p.d1 * p.d0 * 2;
+                    for (int a = 0; a < 2; ++a)
+                        HIPCHK(pack_frag_from_taps_launch((const char*)dst + a * cls_bytes, (char*)packed + h->frag_off[i] + a * cls_bytes, 6,
+                                                          2 * p.d1, p.d0, s));
+                }
+                break;
             case PK_BIAS2:
                 HIPCHK(push_copy(src, (float*)dst, p.d0));
                 HIPCHK(push_copy(src, (float*)dst + p.d0, p.d0));
@@ -1125,6 +1142,8 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
                               nullptr, 0, nullptr, nullptr, XF_NONE, 0, at(w.xd[l - 1], act_bytes(l - 1), ln.b0),
                               at(w.xu[l - 1], act_bytes(l - 1), ln.b0), stats_of(ln, 0), ln.n, H, W};
                 u.groups = true;
+                if ((size_t)c->up_w[l] < c->frag_off.size() && c->frag_off[c->up_w[l]])
+                    u.wf = (const char*)packed + c->frag_off[c->up_w[l]];
                 return run_conv(u, ln.st, &np, &cs);
             }));
             cur = 0;
@@ -1902,6 +1921,20 @@ int ddimx_downsample_wreg_fwd(int Cin, int Cout, const void* x, const void* w_fr
     CHK(conv_plan(d, &pl));
     if (!pl.wreg) return fail("ddimx_downsample_wreg_fwd: %d->%d %dx%d is not eligible for the register-streamed kernel", Cin, Cout, H, W);
     return run_conv(d, (hipStream_t)stream, nullptr, nullptr);
+}
+int ddimx_pack_frag_from_taps(const void* taps, void* dst, int ntaps, int NOUT, int CIN, void* stream) {
+    if (!taps || !dst) return fail("ddimx_pack_frag_from_taps: null argument");
+    HIPCHK(pack_frag_from_taps_launch(taps, dst, ntaps, NOUT, CIN, (hipStream_t)stream));
+    return 0;
+}
+int ddimx_upsample_add_wreg_fwd(int Cin, int Cout, const void* x, const void* w_frag, const float* bias2, const void* skip, void* y,
+                                float* stats, int B, int H, int W, void* stream) {
+    ConvCall u = {DT_BF16, UP4, Cin, Cout, x, w_frag, bias2, nullptr, 0, nullptr, nullptr, XF_NONE, 0, skip, y, stats, B, H, W};
+    u.wf = w_frag;
+    ConvPlan pl;
+    CHK(conv_plan(u, &pl));
+    if (!pl.wreg) return fail("ddimx_upsample_add_wreg_fwd: %d->%d %dx%d is not eligible for the register-streamed kernel", Cin, Cout, H, W);
+    return run_conv(u, (hipStream_t)stream, nullptr, nullptr);
 }
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats,

@@ -14,7 +14,12 @@ namespace ddimx {
     X(64, 96, DOWN4, 4, 16, 2, 3, 8, 1)       \
     X(96, 128, DOWN4, 4, 16, 2, 4, 8, 1)      \
     X(128, 192, DOWN4, 4, 8, 1, 6, 8, 1)     \
-    X(192, 256, DOWN4, 4, 8, 1, 8, 8, 1)
+    X(192, 256, DOWN4, 4, 8, 1, 8, 8, 1)      \
+    X(256, 384, UP4, 4, 8, 1, 4, 8, 3)        \
+    X(192, 256, UP4, 4, 16, 2, 4, 8, 2)       \
+    X(128, 192, UP4, 4, 32, 1, 6, 8, 1)       \
+    X(96, 128, UP4, 4, 32, 1, 4, 6, 1)        \
+    X(64, 64, UP4, 8, 32, 2, 2, 6, 1)
 
 hipError_t wreg_geometry(int mode, int cin, int cout, WregGeom* g) {
 #define DDIMX_G(CI, CO, MO, TH_, TW_, WM_, WN_, D_, NS_)                                                     \

@@ -23,7 +23,8 @@ namespace ddimx {
 
 struct WregArgs {
     const void* in;         // [B][H][W][C] bf16
-    const void* wf;         // fragment-order weights (pack_conv_frag_launch)
+    const void* wf;         // fragment-order weights (pack_conv_frag_launch / pack_frag_from_taps_launch; UP4: [2 classes] of them)
+    const void* skip;       // UP4: tensor of the output's shape added in the epilogue, or null
     const float* bias;      // [C] or null
     const float* chan_add;  // per-sample per-cout vector or null
     int chan_add_stride;
@@ -42,8 +43,12 @@ struct WregArgs {
 template <int CIN_, int COUT_, int MODE_, int TH_, int TW_, int WM_, int WN_, int D_, int NS_ = 1>
 struct WregCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, MODE = MODE_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, D = D_;
-    static_assert(MODE == CONV3 || MODE == DOWN4, "3x3 stride 1 (Residual_Block) or 4x4 stride 2 (Downsample)");
-    static constexpr int NTAPS = MODE == DOWN4 ? 16 : 9, TAPW = MODE == DOWN4 ? 4 : 3, SXY = MODE == DOWN4 ? 2 : 1;
+    // CONV3: 3x3 stride 1 (Residual_Block); DOWN4: 4x4 stride 2 (Downsample); UP4: ConvTranspose2d 4x4 stride 2 (Upsample) as
+    // sub-pixel convolutions exactly as conv_mfma_kernel does them: grid.z = output-row parity, COUT = 2 x the real output
+    // channels (the two column parities side by side: one input pixel -> 2 * Cprev contiguous output elements), 2 x 3 taps of the
+    // input rows vy + cls .. + 1, the skip tensor added in the epilogue (models/diffusion.py:59-67,284).
+    static constexpr int NTAPS = MODE == DOWN4 ? 16 : (MODE == UP4 ? 6 : 9), TAPW = MODE == DOWN4 ? 4 : 3, SXY = MODE == DOWN4 ? 2 : 1;
+    static constexpr int NCLS = MODE == UP4 ? 2 : 1;
     static constexpr int NS = NS_;      // output-channel splits: grid.y workgroups share a pixel tile (the latency-bound deep levels
                                         // have too few pixels to fill 256 CUs otherwise; each stages the small halo for itself)
     static constexpr int NB = COUT / NS;   // output channels of one workgroup
@@ -113,11 +118,12 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     const int t_begin = wg * a.tiles_per_wg;
     const int t_end = (t_begin + a.tiles_per_wg < ntile_s) ? t_begin + a.tiles_per_wg : ntile_s;
     const int cout0 = blockIdx.y * F::NB;
+    const int cls = blockIdx.z;  // UP4: output-row parity; 0 otherwise
 
     // ---- weight fragments: step s of this wave's cout block = one coalesced 16-byte-per-lane load -------------------------
     // (buffer load: resource in SGPRs, ONE per-lane offset register, the step as scalar offset -- 64-bit per-step addresses would be
     // hoisted out of the tile loop by the compiler, two registers per step, and spill)
-    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(a.wf, (unsigned)(F::NTAPS * CIN * COUT * ES));
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc((const char*)a.wf + (size_t)cls * (F::NTAPS * CIN * COUT * ES), (unsigned)(F::NTAPS * CIN * COUT * ES));
     const unsigned wlane = (unsigned)(((cout0 / 32 + wn) * 64 + lane) * 16);
     auto wfrag = [&](int s) __attribute__((always_inline)) -> uint4 {
         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wlane, s * (F::NBLK * 1024), 0);
@@ -132,15 +138,15 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     // them except, in order, the first fragment load.
     {
         u32x4_t wrs;
-        const uint64_t wp = (uint64_t)a.wf;
+        const uint64_t wp = (uint64_t)a.wf + (uint64_t)cls * (F::NTAPS * CIN * COUT * ES);
         wrs[0] = __builtin_amdgcn_readfirstlane((unsigned)wp);
         wrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32));
         wrs[2] = (unsigned)(F::NTAPS * CIN * COUT * ES);
         wrs[3] = 0x00020000u;
         const unsigned sink_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(sink));
         constexpr unsigned NL = (unsigned)F::NTAPS * CIN * COUT * ES / 128u;
-        const unsigned nsl = (gridDim.x * gridDim.y + 7u) >> 3;
-        const unsigned slice = (blockIdx.y * gridDim.x + blockIdx.x) >> 3;
+        const unsigned nsl = (gridDim.x * gridDim.y + 7u) >> 3;  // workgroups per XCD of ONE class
+        const unsigned slice = (blockIdx.y * gridDim.x + blockIdx.x) >> 3;  // (per row-parity class: its own weight tensor)
 #pragma unroll 1
         for (unsigned k = 0; (k * F::NWAVES * nsl) * 64u < NL; ++k) {
             const unsigned line = ((k * F::NWAVES + (unsigned)wave) * nsl + slice) * 64u + (unsigned)lane;
@@ -220,16 +226,18 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
 #pragma unroll
     for (int m = 0; m < F::MT; ++m) {
         const int p = (wm * F::MT + m) * 32 + l31;
-        pixoff[m] = (p / TW) * SXY * F::ROWSTRIDE + (p % TW) * SXY * F::PSTRIDE + h * 16;
+        pixoff[m] = ((p / TW) * SXY + (F::MODE == UP4 ? cls : 0)) * F::ROWSTRIDE + (p % TW) * SXY * F::PSTRIDE + h * 16;
     }
     const int oc = tid % F::OLPP, oslot = tid / F::OLPP;
     const bool ovalid = oc < F::OPP;
     f32x2_t st_s[NP], st_q[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
-    const int Ho = a.H / SXY, Wo = a.W / SXY;  // output image
+    // output image: Ho rows of Wo "virtual" pixels x COUT (UP4: 2 * H rows, each virtual pixel = two real ones side by side)
+    const int Ho = F::MODE == UP4 ? 2 * a.H : a.H / SXY, Wo = a.W / SXY;
     const unsigned out_bytes = (unsigned)((size_t)Ho * Wo * COUT * ES);
     const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc((T*)a.out + (size_t)bs * Ho * Wo * COUT, out_bytes);
+    const __amdgpu_buffer_rsrc_t skip_rsrc = make_rsrc(a.skip ? (const T*)a.skip + (size_t)bs * Ho * Wo * COUT : (const T*)a.out, a.skip ? out_bytes : 0u);
 
     // ---- prologue (as conv_mfma_kernel): addend, GroupNorm input, first halo -------------------------------------------------
     constexpr int AIT = (F::NB + F::NTHREADS - 1) / F::NTHREADS;
@@ -346,25 +354,46 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
         __syncthreads();  // barrier B: output tile complete
         DDIMX_STAMP_AT(5);
 
-        // ---- epilogue 2: whole pixel rows leave with 16-byte stores; statistics of the values as stored --------------------------
-        if (ovalid) {
+        // ---- epilogue 2: whole pixel rows leave with 16-byte stores (+ skip tensor); statistics of the values as stored ------------
+        auto epi2 = [&](auto skip_tag) __attribute__((always_inline)) {
+            constexpr bool SKIP = decltype(skip_tag)::value;
+            if (!ovalid) return;
             const unsigned cbase = (unsigned)(cout0 * ES + oc * 16);
+            unsigned offs[F::NPASS];
+            uint4 skv[SKIP ? F::NPASS : 1];
+#pragma unroll
+            for (int k = 0; k < F::NPASS; ++k) {  // all skip loads of the tile in flight before the first store
+                const int p = oslot + k * F::STEP;
+                const int vy = y0 + p / TW, vx = x0 + p % TW;
+                const bool in = F::P % F::STEP == 0 || p < F::P;
+                const int oy = F::MODE == UP4 ? 2 * vy + cls : vy;
+                offs[k] = in ? (unsigned)((oy * Wo + vx) * COUT * ES) + cbase : kOOB;
+                if (SKIP) skv[k] = buf_load16(skip_rsrc, offs[k]);
+            }
 #pragma unroll
             for (int k = 0; k < F::NPASS; ++k) {
                 const int p = oslot + k * F::STEP;
                 if (F::P % F::STEP != 0 && p >= F::P) break;
-                const int vy = y0 + p / TW, vx = x0 + p % TW;
-                const uint4 v = *(const uint4*)(otile + p * F::OSTRIDE + oc * 16);
-                buf_store16(out_rsrc, (unsigned)((vy * Wo + vx) * COUT * ES) + cbase, v);
+                uint4 v = *(const uint4*)(otile + p * F::OSTRIDE + oc * 16);
                 f32x2_t f[NP];
                 Pairs<T>::unpack(v, f);
+                if (SKIP) {
+                    f32x2_t kk[NP];
+                    Pairs<T>::unpack(skv[k], kk);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) f[j] += kk[j];
+                    v = Pairs<T>::pack(f);
+                    Pairs<T>::unpack(v, f);  // statistics of the values as stored
+                }
+                buf_store16(out_rsrc, offs[k], v);
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     st_s[j] += f[j];
                     st_q[j] = fma2(f[j], f[j], st_q[j]);
                 }
             }
-        }
+        };
+        if (a.skip) epi2(std::true_type()); else epi2(std::false_type());
         DDIMX_STAMP_AT(6);
         if (++tx == a.tiles_x) { tx = 0; ++ty; }
         if (t + 1 < t_end) {
@@ -403,17 +432,18 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
             }
         }
         __syncthreads();
-        const int nparts = a.wgs_per_sample;
+        const int nparts = a.wgs_per_sample * F::NCLS;
+        const int part = wg * F::NCLS + cls;
         if (a.stats_groups_c) {
             if (wave == 0)
                 gn_bins_store<F::NWAVES>(red, F::NB * 2, F::NB, cout0, a.stats_groups_c,
-                                         a.stats + (((size_t)bs * nparts + wg) * F::NS + blockIdx.y) * kGnSlab, lane);
+                                         a.stats + (((size_t)bs * nparts + part) * F::NS + blockIdx.y) * kGnSlab, lane);
         } else {
             for (int i = tid; i < F::NB * 2; i += F::NTHREADS) {
                 float tt = 0.f;
 #pragma unroll
                 for (int w = 0; w < F::NWAVES; ++w) tt += red[w * F::NB * 2 + i];
-                a.stats[(((size_t)bs * nparts + wg) * COUT + cout0) * 2 + i] = tt;
+                a.stats[(((size_t)bs * nparts + part) * COUT + cout0) * 2 + i] = tt;
             }
         }
     }
@@ -429,12 +459,14 @@ hipError_t launch_wreg_cfg(const WregArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv3_wreg_kernel<F>, dim3(a.wgs_per_sample * a.B, F::NS), dim3(F::NTHREADS), F::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(conv3_wreg_kernel<F>, dim3(a.wgs_per_sample * a.B, F::NS, F::NCLS), dim3(F::NTHREADS), F::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
 // conv_inst_bf16_wreg.hip
 struct WregGeom { int th, tw, lds_bytes, nthreads, nsplit; };
+// packed tap layout [ntaps][NOUT][CIN] bf16 (ddimx_pack_conv / one row-parity class of ddimx_pack_convT) -> fragment order
+hipError_t pack_frag_from_taps_launch(const void* src, void* dst, int ntaps, int NOUT, int CIN, hipStream_t s);
 hipError_t wreg_geometry(int mode, int cin, int cout, WregGeom* g);
 hipError_t wreg_launch(int mode, int cin, int cout, const WregArgs& a, hipStream_t stream);
 // weights [O][I][KH][KW] fp32 -> bf16 fragment order [KH*KW * I/16][O/32][64][8]  (kernels.hip)

@@ -1257,6 +1257,27 @@ hipError_t pack_conv_frag_launch(const float* w, void* dst, int O, int I, int KK
     return hipGetLastError();
 }
 
+// packed taps [ntaps][NOUT][CIN] bf16 -> fragment order [ntaps * CIN/16][NOUT/32][64][8] (conv_wreg.h)
+__global__ void pack_frag_from_taps_kernel(const __bf16* __restrict__ src, __bf16* __restrict__ dst, int ntaps, int NOUT, int CIN) {
+    const int KG = CIN / 16, NBLK = NOUT / 32;
+    const long long n = (long long)ntaps * NOUT * CIN;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long long blk = i >> 9;
+        const int nb = (int)(blk % NBLK), st = (int)(blk / NBLK);
+        const int tap = st / KG, kg = st % KG;
+        const int co = nb * 32 + (lane & 31), ci = kg * 16 + (lane >> 5) * 8 + j;
+        dst[i] = src[((size_t)tap * NOUT + co) * CIN + ci];
+    }
+}
+hipError_t pack_frag_from_taps_launch(const void* src, void* dst, int ntaps, int NOUT, int CIN, hipStream_t s) {
+    if (NOUT % 32 || CIN % 16) return hipErrorInvalidValue;
+    const long long n = (long long)ntaps * NOUT * CIN;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_frag_from_taps_kernel, dim3(blocks), dim3(256), 0, s, (const __bf16*)src, (__bf16*)dst, ntaps, NOUT, CIN);
+    return hipGetLastError();
+}
+
 // ConvTranspose2d(k4,s2,p1) weight [I][O][4][4] -> sub-pixel form [a][tap=(dyi,dx)][vc=b*O+co][ci]:
 // output (2py+a, 2px+b) reads input (py+dy-1, px+dx-1) through kernel element kh = 3+a-2dy, kw = 3+b-2dx
 // (dy = a+dyi in {a,a+1}; dx in {0,1,2}); combinations whose kw falls outside 0..3 are zero.

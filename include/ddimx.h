@@ -217,6 +217,12 @@ int ddimx_debug_set_stamps(unsigned long long* stamps);
 int ddimx_pack_conv_frag_k(const float* w, void* dst, int O, int I, int KK, void* stream);
 int ddimx_downsample_wreg_fwd(int Cin, int Cout, const void* x, const void* w_frag, const float* bias, void* y, float* stats, int B,
                               int H, int W, void* stream);
+/* Upsample.forward + the skip addition (models/diffusion.py:59-67,284) through the register-streamed kernel: w_frag = both
+ * row-parity classes of the sub-pixel form (ddimx_pack_convT) re-ordered by ddimx_pack_frag_from_taps(class a of the convT
+ * packing, 6 taps, NOUT = 2 * Cout, Cin) one after the other; bias2, skip, y, stats as ddimx_upsample_add_fwd. */
+int ddimx_pack_frag_from_taps(const void* taps, void* dst, int ntaps, int NOUT, int CIN, void* stream);
+int ddimx_upsample_add_wreg_fwd(int Cin, int Cout, const void* x, const void* w_frag, const float* bias2, const void* skip, void* y,
+                                float* stats, int B, int H, int W, void* stream);
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                            float* stats, int B, int H, int W, void* stream);

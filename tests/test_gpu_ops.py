@@ -363,3 +363,39 @@ def test_wreg_downsample_vs_fp32_reference(cin, cout, hw):
     gs = got.double()
     assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(256, 192, (8, 16)), (192, 128, (8, 32)), (128, 96, (8, 64)), (96, 64, (8, 64)), (64, 32, (16, 64))])
+def test_wreg_upsample_add_vs_fp32_reference(cin, cout, hw):
+    """Upsample = ConvTranspose2d(k4, s2, p1) + bias, then the skip addition (models/diffusion.py:59-67,284) through the
+    register-streamed-weights kernel (both row-parity classes, the two column parities as 2 * Cout virtual channels): against fp32
+    torch on the same bf16-rounded operands, plus the statistics of the stored values."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    dt, b = G.BF16, 2
+    h, w = hw
+    dev = G.dev()
+    x = (synth.gaussian(f"wup.x{cin}", (b, cin, h, w)) * 1.1).bfloat16().float()
+    skip = synth.gaussian(f"wup.s{cin}", (b, cout, 2 * h, 2 * w)).bfloat16().float()
+    wt = synth.gaussian(f"wup.w{cin}", (cin, cout, 4, 4)) / (4 * cin) ** 0.5
+    bias = synth.gaussian(f"wup.b{cin}", (cout,)) * 0.3
+    xn, sn = G.to_nhwc(x, dt), G.to_nhwc(skip, dt)
+    wp = G.pack_convT(wt, dt)                       # [2][6][2*cout][cin]
+    wf = torch.empty_like(wp)
+    per = 6 * 2 * cout * cin
+    for a in range(2):
+        _lib.check(lib.ddimx_pack_frag_from_taps(_lib.ptr(wp[a * per:]), _lib.ptr(wf[a * per:]), 6, 2 * cout, cin, _lib.stream()))
+    b2 = torch.cat([bias, bias]).to(dev)
+    y = torch.empty_like(sn)
+    stats = torch.zeros(b * 4 * h * w * cout * 2 // 8 + 8192, device=dev)
+    _lib.check(lib.ddimx_upsample_add_wreg_fwd(cin, cout, _lib.ptr(xn), _lib.ptr(wf), _lib.ptr(b2), _lib.ptr(sn), _lib.ptr(y), _lib.ptr(stats),
+                                               b, h, w, _lib.stream()))
+    torch.cuda.synchronize()
+    got = G.from_nhwc(y, dt)
+    want = F.conv_transpose2d(x, wt.bfloat16().float(), bias, stride=2, padding=1) + skip
+    G.check_close(got, want, dt, f"wreg up {cin}->{cout} {hw}")
+    # per-channel statistics come in 2 * cout virtual channels (the two column parities): fold them
+    st = stats.cpu()[: (stats.numel() // (4 * cout)) * 4 * cout].view(-1, 2, cout, 2).double().sum(dim=(0, 1))
+    gs = got.double()
+    assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
