@@ -34,7 +34,11 @@ struct Knobs {
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
         two_tiles = geti("DDIMX_TWO_TILES", 0);
         conv_stagger = geti("DDIMX_CONV_STAGGER", 0);
-        conv_fold = geti("DDIMX_CONV_FOLD", 1);
+        // the folded-affine kernel (conv_fold.h) for the block's second conv at C = 32: OFF in the walk.  Alone it is faster than the
+        // register-transform kernel (74 vs 80 us per launch in the unforked step), but with two batch shards in flight the step is
+        // 0.9 % slower (2 208 vs 2 228 sample-fwd/s, same box: DESIGN section 9).  1 = on (A/B); the kernel stays reachable and
+        // tested through ddimx_conv3x3_fold_fwd.
+        conv_fold = geti("DDIMX_CONV_FOLD", 0);
         conv_wreg = geti("DDIMX_CONV_WREG", 1);  // A/B hook: 0 = the 3x3 convs of C >= 64 keep the LDS weight ring (conv_mfma_kernel)  // A/B hook: 0 = the affine-input 3x3 convs keep the register-transform kernel
     }
 };
