@@ -6,7 +6,7 @@ namespace ddimx {
 //      CIN  COUT  MODE   TH  TW  WM WN  D  NS
 #define DDIMX_WREG(X)                         \
     X(64, 64, CONV3, 8, 32, 2, 2, 6, 1)       \
-    X(96, 96, CONV3, 8, 32, 2, 3, 6, 1)       \
+    X(96, 96, CONV3, 8, 32, 4, 3, 6, 1)       \
     X(128, 128, CONV3, 4, 32, 2, 2, 8, 2)     \
     X(192, 192, CONV3, 4, 16, 2, 2, 12, 3)    \
     X(256, 256, CONV3, 4, 8, 1, 2, 16, 4)     \
