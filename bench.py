@@ -71,13 +71,27 @@ def per_kernel_times(model, B, T, reps=20):
         stats = torch.empty(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)) + 2 * B * C * 4096, device=dev)
         st = _lib.stream()
 
+        wreg = bf16 and C >= 64  # the inference walk's kernel from C = 64 up: weights streamed to registers (csrc/conv_wreg.h)
+        if wreg:
+            w_f32 = torch.randn(C, C, 3, 3, device=dev) * (1.0 / (9 * C) ** 0.5)
+            wfr = torch.empty(9 * C * C, dtype=tdt, device=dev)
+            _lib.check(lib.ddimx_pack_conv_frag(_lib.ptr(w_f32), _lib.ptr(wfr), C, C, st))
+
         def conv():  # K1 of the block: GroupNorm affine + SiLU prologue, + timestep embedding, SiLU
-            _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale),
-                                             _lib.ptr(shift), 2, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+            if wreg:
+                _lib.check(lib.ddimx_conv3x3_wreg_fwd(C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(wfr), None, _lib.ptr(temb), C, _lib.ptr(scale),
+                                                      _lib.ptr(shift), 2, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+            else:
+                _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale),
+                                                 _lib.ptr(shift), 2, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
 
         def conv2():  # K2 of the block: GroupNorm affine prologue, + bias, SiLU
-            _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), None, 0, _lib.ptr(scale),
-                                             _lib.ptr(shift), 1, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+            if wreg:
+                _lib.check(lib.ddimx_conv3x3_wreg_fwd(C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(wfr), _lib.ptr(bias), None, 0, _lib.ptr(scale),
+                                                      _lib.ptr(shift), 1, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+            else:
+                _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), None, 0, _lib.ptr(scale),
+                                                 _lib.ptr(shift), 1, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
 
         def resid():
             _lib.check(lib.ddimx_resid_gn_fwd(dt, C, _lib.ptr(x), _lib.ptr(h), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
@@ -86,7 +100,8 @@ def per_kernel_times(model, B, T, reps=20):
         elems = B * H * W * C
         tc1, tc2, tr = timed(conv), timed(conv2), timed(resid)
         tc = 0.5 * (tc1 + tc2)
-        rows.append(dict(kernel=f"conv_mfma_kernel<{'bf16' if bf16 else 'f32'},C={C},3x3>", level=lvl, launches_per_fwd=4 * res,
+        kname = f"conv3_wreg_kernel<bf16,C={C},3x3>" if wreg else f"conv_mfma_kernel<{'bf16' if bf16 else 'f32'},C={C},3x3>"
+        rows.append(dict(kernel=kname, level=lvl, launches_per_fwd=4 * res,
                          seconds=tc, seconds_k1=tc1, seconds_k2=tc2, alg_bytes=2 * elems * es + 9 * C * C * es, flops=2.0 * elems * 9 * C))
         rows.append(dict(kernel=f"resid_kernel<{'bf16' if bf16 else 'f32'},C={C}>", level=lvl, launches_per_fwd=2 * res,
                          seconds=tr, alg_bytes=3 * elems * es, flops=3.0 * elems))
@@ -98,16 +113,34 @@ def per_kernel_times(model, B, T, reps=20):
             bu = torch.randn(2 * Cp, device=dev) * 0.1
             zp = torch.empty_like(xp)
 
+            if bf16:  # fragment-order copies for the register-streamed kernels (what the walk launches)
+                wd_f32 = torch.randn(C, Cp, 4, 4, device=dev) * (1.0 / (16 * Cp) ** 0.5)
+                wdf = torch.empty(16 * C * Cp, dtype=tdt, device=dev)
+                _lib.check(lib.ddimx_pack_conv_frag_k(_lib.ptr(wd_f32), _lib.ptr(wdf), C, Cp, 16, st))
+                wuf = torch.empty_like(wu)
+                per = 6 * 2 * Cp * C
+                for a_ in range(2):
+                    _lib.check(lib.ddimx_pack_frag_from_taps(_lib.ptr(wu[a_ * per:]), _lib.ptr(wuf[a_ * per:]), 6, 2 * Cp, C, st))
+                sdn = torch.empty(B * H * W * C * 2 // 8 + 8192, device=dev)
+                sup = torch.empty(B * Hp * Wp * Cp * 2 // 8 + 8192, device=dev)
+
             def down():
-                _lib.check(lib.ddimx_downsample_fwd(dt, Cp, C, _lib.ptr(xp), _lib.ptr(wd), _lib.ptr(bias), _lib.ptr(y), B, Hp, Wp, st))
+                if bf16:
+                    _lib.check(lib.ddimx_downsample_wreg_fwd(Cp, C, _lib.ptr(xp), _lib.ptr(wdf), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(sdn), B, Hp, Wp, st))
+                else:
+                    _lib.check(lib.ddimx_downsample_fwd(dt, Cp, C, _lib.ptr(xp), _lib.ptr(wd), _lib.ptr(bias), _lib.ptr(y), B, Hp, Wp, st))
 
             def up():
-                _lib.check(lib.ddimx_upsample_add_fwd(dt, C, Cp, _lib.ptr(x), _lib.ptr(wu), _lib.ptr(bu), _lib.ptr(xp), _lib.ptr(zp), B, H, W, st))
+                if bf16:
+                    _lib.check(lib.ddimx_upsample_add_wreg_fwd(C, Cp, _lib.ptr(x), _lib.ptr(wuf), _lib.ptr(bu), _lib.ptr(xp), _lib.ptr(zp), _lib.ptr(sup), B, H, W, st))
+                else:
+                    _lib.check(lib.ddimx_upsample_add_fwd(dt, C, Cp, _lib.ptr(x), _lib.ptr(wu), _lib.ptr(bu), _lib.ptr(xp), _lib.ptr(zp), B, H, W, st))
 
             ep = B * Hp * Wp * Cp
-            rows.append(dict(kernel=f"conv_mfma_kernel<down4 {Cp}->{C}>", level=lvl, launches_per_fwd=1, seconds=timed(down),
+            fam = "conv3_wreg_kernel" if bf16 else "conv_mfma_kernel"
+            rows.append(dict(kernel=f"{fam}<down4 {Cp}->{C}>", level=lvl, launches_per_fwd=1, seconds=timed(down),
                              alg_bytes=(ep + elems) * es + 16 * C * Cp * es, flops=2.0 * elems * 16 * Cp))
-            rows.append(dict(kernel=f"conv_mfma_kernel<up4 {C}->{Cp} + skip>", level=lvl, launches_per_fwd=1, seconds=timed(up),
+            rows.append(dict(kernel=f"{fam}<up4 {C}->{Cp} + skip>", level=lvl, launches_per_fwd=1, seconds=timed(up),
                              alg_bytes=(elems + 2 * ep) * es + 16 * C * Cp * es, flops=2.0 * ep * 4 * C))
             del xp, zp
         del x, y, h, stats
