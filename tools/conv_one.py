@@ -25,8 +25,17 @@ scale = torch.rand(B, C, device=dev) + 0.5
 shift = torch.randn(B, C, device=dev) * 0.1
 stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)), device=dev)
 bias = torch.randn(C, device=dev) * 0.1
+wreg = C >= 64 and os.environ.get("DDIMX_ONE_WREG", "1") != "0"  # what the inference walk launches from C = 64 up (csrc/conv_wreg.h)
+if wreg:
+    wt = torch.randn(C, C, 3, 3, device=dev) * (1.0 / (9 * C) ** 0.5)
+    wf = torch.empty(9 * C * C, dtype=tdt, device=dev)
+    _lib.check(lib.ddimx_pack_conv_frag(_lib.ptr(wt), _lib.ptr(wf), C, C, _lib.stream()))
 for _ in range(reps):
-    if xf == 2:
+    if wreg:
+        _lib.check(lib.ddimx_conv3x3_wreg_fwd(C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(wf), None if xf == 2 else _lib.ptr(bias),
+                                              _lib.ptr(temb) if xf == 2 else None, C, _lib.ptr(scale), _lib.ptr(shift), xf, 1,
+                                              _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+    elif xf == 2:
         _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(temb), C, _lib.ptr(scale), _lib.ptr(shift), 2, 1,
                                          _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
     else:
