@@ -529,9 +529,9 @@ hipError_t gn_finalize_launch(const float* stats, int nparts, int Cs, int C, dou
 
 // The same from group-format partials (gn_fused.h) -- used where a sample has more than kGnFuseMaxParts partials (long
 // spectrograms at the shallow levels), so that consumers need not re-read them per workgroup.  One block per sample.
-__global__ void __launch_bounds__(512) gn_finalize_groups_kernel(const GnIn gn, int C, float* __restrict__ scale,
-                                                                 float* __restrict__ shift) {
-    __shared__ float scr[8 * kGroups * 2];
+__global__ void __launch_bounds__(1024) gn_finalize_groups_kernel(const GnIn gn, int C, float* __restrict__ scale,
+                                                                  float* __restrict__ shift) {
+    __shared__ float scr[16 * kGroups * 2];
     const int b = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
     GnInLoads ld;
     gn_in_issue(gn, b, tid, bd, ld);
@@ -545,10 +545,10 @@ __global__ void __launch_bounds__(512) gn_finalize_groups_kernel(const GnIn gn, 
         shift[(size_t)b * C + c] = fmaf(-m, sc, gn.beta ? gn.beta[c] : 0.f);
     }
 }
-// nthreads: the block size of the consumer this replaces the in-kernel finalisation of (64 .. 512, a multiple of 64) -- the
+// nthreads: the block size of the consumer this replaces the in-kernel finalisation of (64 .. 1024, a multiple of 64) -- the
 // reduction order, and with it every bit of the result, is a function of (gn.np, nthreads)
 hipError_t gn_finalize_groups_launch(const GnIn& gn, int C, float* scale, float* shift, int B, int nthreads, hipStream_t s) {
-    if (C % kGroups || nthreads < 64 || nthreads > 512 || nthreads % 64) return hipErrorInvalidValue;
+    if (C % kGroups || nthreads < 64 || nthreads > 1024 || nthreads % 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(B), dim3(nthreads), 0, s, gn, C, scale, shift);
     return hipGetLastError();
 }
