@@ -208,6 +208,35 @@ def test_sampler_eta_nonzero_matches_oracle_with_the_drawn_noise(eta):
     assert not torch.allclose(xs0[-2], xs[-2], rtol=1e-3, atol=1e-3)
 
 
+# ------------------------------------------------------------------------------------------------- the full schedule
+def test_generalized_steps_over_the_full_1000_entry_schedule_vs_oracle():
+    """functions/denoising.py:10-52 with ``seq = range(1000)`` -- the step count of BASELINE configs[1] and configs[4] -- on the
+    tiny network in fp32: 1000 U-Net evaluations through the hipGraph-replayed step against the CPU oracle's loop around its own
+    forward (about 10 s of CPU).  Judged on the final x0 prediction and the final x (the trajectory feeds every step's error
+    into the next 999, hence the per-forward gate x 30), plus ``select_index`` semantics at this length and graph == eager."""
+    cfg, m = _eval_model("torch.cuda.FloatTensor", tiny=True, seed=3)
+    alphas = make_schedule(cfg.diffusion)[1]
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ocfg = configs.tiny_config("torch.FloatTensor")
+    seq = list(range(1000))
+    x = synth.gaussian("full_schedule.x", (2, 2, 16, 32))
+    sel = [0, 499, -1]
+    xs, x0 = D.generalized_steps(x.cuda().clone(), seq, m, alphas, sel, eta=0.0)
+    with torch.no_grad():
+        exs, ex0 = ref_cpu.generalized_steps(x.clone(), seq, lambda a, t: ref_cpu.model_forward(sd, ocfg, a, t), alphas, sel, eta=0.0)
+    assert len(xs) == len(exs) == 4 and len(x0) == len(ex0) == 3
+    for k in range(3):
+        G.check_close(x0[k].cpu(), ex0[k], G.F32, f"x0 prediction at selected step {sel[k]}", scale=30.0)
+        G.check_close(xs[k + 1].cpu(), exs[k + 1], G.F32, f"x at selected step {sel[k]}", scale=30.0)
+    assert torch.isfinite(xs[-1]).all()
+    os.environ["DDIMX_GRAPH"] = "0"
+    try:
+        xs2, _ = D.generalized_steps(x.cuda().clone(), seq, m, alphas, [-1], eta=0.0)
+    finally:
+        os.environ["DDIMX_GRAPH"] = "1"
+    assert torch.equal(xs2[-1].cpu(), xs[-1].cpu()), "graph replay and eager stepping differ after 1000 steps"
+
+
 # ------------------------------------------------------------------------------------------------- two ranks
 def _rank_main(rank, world, port, ret):
     import torch.distributed as dist
