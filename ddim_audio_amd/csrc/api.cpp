@@ -22,6 +22,7 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
+    int fnet_dense;
     int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold, conv_wreg;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -31,6 +32,7 @@ struct Knobs {
         gn_dbg = geti("DDIMX_GN_DBG", 0);  // A/B hook: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
+        fnet_dense = geti("DDIMX_FNET_DENSE", 1);
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
         two_tiles = geti("DDIMX_TWO_TILES", 0);
         conv_stagger = geti("DDIMX_CONV_STAGGER", 0);
@@ -150,6 +152,13 @@ struct ddimx_ctx {
     int ln0_w, ln0_b, proj_w, proj_b, cout_w, cout_b;
     struct FL { int ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b; };
     std::vector<FL> fl;
+    // second copies for fnet_dense_kernel (fnet_dense.hip; offsets into the packed buffer, 0 = none): the first FFN matrix with
+    // the preceding LayerNorm's gamma folded in (+ the bias with its beta), compute_out likewise with the last layer's output
+    // LayerNorm; all of them in MFMA fragment order and -- bf16 FNet -- pre-rounded to bf16
+    struct FX { size_t w1f, b1f, w2c; };
+    std::vector<FX> fx;
+    size_t fx_proj = 0, fx_coutf = 0, fx_coutb = 0;
+    bool fx_on = false;
     std::vector<int> emb_off_down, emb_off_up;  // temb chunk offsets per block, execution order
     const unsigned long long* dropout_ctr = nullptr;  // device counter added to every dropout seed (ddimx_set_dropout_counter)
 };
@@ -293,6 +302,21 @@ static int build_plan(ddimx_ctx* c) {
     }
     c->cout_w = add_spec(c, "transformer.compute_out.weight", PK_PERM_ROWS, width, hid);
     c->cout_b = add_spec(c, "transformer.compute_out.bias", PK_PERM_COLS, 1, width);
+    c->fx_on = f.fnet_layers > 0 && hid == 512 && inter % 512 == 0 && width % 512 == 0;  // (row statistics: hid / 16 <= 32 parts)
+    if (c->fx_on) {
+        const size_t wes = c->fnet_bf16 ? 2 : 4;
+        auto take = [&](size_t bytes) { const size_t o = c->packed_bytes; c->packed_bytes += al256(bytes); return o; };
+        for (int i = 0; i < f.fnet_layers; ++i) {
+            ddimx_ctx::FX x;
+            x.w1f = take((size_t)inter * hid * wes);
+            x.b1f = take((size_t)inter * 4);
+            x.w2c = take((size_t)hid * inter * wes);
+            c->fx.push_back(x);
+        }
+        c->fx_proj = take((size_t)hid * width * wes);
+        c->fx_coutf = take((size_t)width * hid * wes);
+        c->fx_coutb = take((size_t)width * 4);
+    }
     // timestep-embedding chunk offsets in execution order (models/diffusion.py:178-184,249-250)
     int off = 0;
     for (int l = 0; l < L; ++l)
@@ -329,6 +353,7 @@ struct Ws {
     void *h1, *h2;
     float *stats, *stats2, *scale, *shift;  // stats / stats2: the inference walk alternates (a kernel reads one, writes the other)
     float *ln0, *X, *Ut, *Z, *Y, *Hb, *O, *gpart;
+    float *pz, *pv, *zc, *hc, *vc;  // fnet_dense.hip: row statistics of Z and of the last FFN output; chunk-major Z, FFN hidden, last FFN output
     size_t total;
     size_t stats_per_sample, gpart_per_sample;  // floats: the statistics / split-K scratch one sample can need (max over ops)
     size_t h_per_sample;                        // bytes of h1 / h2 one sample can need (its largest level)
@@ -418,6 +443,11 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
     w->Y = (float*)cv.take(M * hid * 4);
     w->Hb = (float*)cv.take(M * inter * 4);
     w->O = (float*)cv.take(M * c->width * 4);
+    w->pz = (float*)cv.take((size_t)B * (hid / 16) * 64 * 4);  // (blocks of 32 rows per sample whatever S)
+    w->pv = (float*)cv.take((size_t)B * (hid / 32) * 64 * 4);
+    w->zc = (float*)cv.take((size_t)B * 32 * hid * 4);
+    w->hc = (float*)cv.take((size_t)B * 32 * inter * 4);
+    w->vc = (float*)cv.take((size_t)B * 32 * hid * 4);
     {   // split-K partial tiles of the skinny FNet GEMMs
         const int bf = c->fnet_bf16;
         const int shp[6][5] = {{(int)M, hid, c->width, 1, bf}, {2 * hid, S, hid, B, 0}, {S, hid, S, B, 0},
@@ -878,6 +908,48 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     const int bf = c->fnet_bf16;
     HIPCHK(layernorm_launch(c->dtype, x, tb->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps, w.ln0, M,
                             width, s));
+    if (c->fx_on && knobs().fnet_dense != 0 && knobs().fnet_mix != 0 && fnet_mix_supported(S, hid) &&
+        fnet_dense_supported(S, hid, inter) && fnet_dense_supported(S, inter, hid) && fnet_dense_supported(S, width, hid) &&
+        fnet_dense_supported(S, hid, width)) {
+        // Three or four launches per layer instead of six (fnet_dense.hip): the Fourier mixing also emits the row statistics of
+        // its output; the first FFN matrix normalises its operand from them (gamma / beta folded into the packed weights) and
+        // applies bias + gelu_new; the second adds bias and the recomputed LayerNorm(Z) residual; the output LayerNorm keeps a
+        // launch, except the last one, which compute_out absorbs the same way.
+        const char* pk = (const char*)packed;
+        const int npz = hid / 16, npv = hid / 32;
+        FnetDenseArgs d;
+        memset(&d, 0, sizeof(d));
+        d.eps = eps; d.S = S;
+        d.W = pk + c->fx_proj; d.bias = pf(c, packed, c->proj_b); d.X = w.ln0; d.out = w.X; d.K = width; d.N = hid;
+        HIPCHK(fnet_dense_launch(d, B, bf, s));
+        float* cur = w.X;
+        for (int i = 0; i < f.fnet_layers; ++i) {
+            const ddimx_ctx::FL& L = c->fl[i];
+            const ddimx_ctx::FX& X = c->fx[i];
+            const bool last = i == f.fnet_layers - 1;
+            HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, cur, nullptr, B, S, hid, s, w.zc, w.pz));
+            memset(&d, 0, sizeof(d));
+            d.eps = eps; d.S = S;
+            d.W = pk + X.w1f; d.bias = (const float*)(pk + X.b1f); d.X = w.zc; d.x_chunk = 1; d.xstats = w.pz; d.xnp = npz; d.xn = 16;
+            d.out = w.hc; d.out_chunk = 1; d.out_bf16 = bf; d.act = 1; d.K = hid; d.N = inter;
+            HIPCHK(fnet_dense_launch(d, B, bf, s));
+            memset(&d, 0, sizeof(d));
+            d.eps = eps; d.S = S;
+            d.W = pk + X.w2c; d.bias = pf(c, packed, L.b2); d.X = w.hc; d.x_chunk = 1; d.x_bf16 = bf; d.K = inter; d.N = hid;
+            d.out = last ? w.vc : w.Y; d.out_chunk = last;
+            d.R = w.zc; d.rstats = w.pz; d.rgamma = pf(c, packed, L.ln1_w); d.rbeta = pf(c, packed, L.ln1_b); d.rnp = npz; d.rn = 16;
+            d.ostats = last ? w.pv : nullptr;
+            HIPCHK(fnet_dense_launch(d, B, bf, s));
+            if (!last)
+                HIPCHK(layernorm_launch(DT_F32, w.Y, nullptr, 1, pf(c, packed, L.ln2_w), pf(c, packed, L.ln2_b), eps, cur, M, hid, s));
+        }
+        memset(&d, 0, sizeof(d));
+        d.eps = eps; d.S = S;
+        d.W = pk + c->fx_coutf; d.bias = (const float*)(pk + c->fx_coutb); d.X = w.vc; d.x_chunk = 1; d.xstats = w.pv; d.xnp = npv; d.xn = 32;
+        d.out = w.O; d.K = hid; d.N = width;
+        HIPCHK(fnet_dense_launch(d, B, bf, s));
+        return 0;
+    }
     CHK(fnet_gemm(w, s, w.ln0, pf(c, packed, c->proj_w), w.X, M, hid, width, width, width, hid, pf(c, packed, c->proj_b),
                   nullptr, 0, 0, bf, 1, 0, 0, 0, S));
     float* cur = w.X;
@@ -991,6 +1063,23 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         }
     }
     HIPCHK(pack_copy_multi_launch(batch, s));
+    if (h->fx_on) {  // from the packed fp32 copies just written (stream order)
+        const ddimx_ctx* c = h;
+        const ddimx_config& f = c->cfg;
+        const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, bf = c->fnet_bf16;
+        char* pk = (char*)packed;
+        for (int i = 0; i < f.fnet_layers; ++i) {
+            const ddimx_ctx::FL& L = c->fl[i];
+            const ddimx_ctx::FX& x = c->fx[i];
+            HIPCHK(fnet_fold_launch(pf(c, packed, L.w1), pf(c, packed, L.ln1_w), pf(c, packed, L.ln1_b), pf(c, packed, L.b1),
+                                    pk + x.w1f, bf, (float*)(pk + x.b1f), inter, hid, s));
+            HIPCHK(fnet_fold_launch(pf(c, packed, L.w2), nullptr, nullptr, nullptr, pk + x.w2c, bf, nullptr, hid, inter, s));
+        }
+        HIPCHK(fnet_fold_launch(pf(c, packed, c->proj_w), nullptr, nullptr, nullptr, pk + c->fx_proj, bf, nullptr, hid, width, s));
+        const ddimx_ctx::FL& LL = c->fl[f.fnet_layers - 1];
+        HIPCHK(fnet_fold_launch(pf(c, packed, c->cout_w), pf(c, packed, LL.ln2_w), pf(c, packed, LL.ln2_b), pf(c, packed, c->cout_b),
+                                pk + c->fx_coutf, bf, (float*)(pk + c->fx_coutb), width, hid, s));
+    }
     return 0;
 }
 
@@ -1119,6 +1208,9 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
         v.ln0 = w.ln0 + rows * c->width; v.X = w.X + rows * f.fnet_hidden; v.Z = w.Z + rows * f.fnet_hidden;
         v.Y = w.Y + rows * f.fnet_hidden; v.Hb = w.Hb + rows * f.fnet_inter; v.O = w.O + rows * c->width;
         v.Ut = w.Ut + (size_t)ln.b0 * 2 * f.fnet_hidden * S;
+        v.pz = w.pz + (size_t)ln.b0 * (f.fnet_hidden / 16) * 64; v.pv = w.pv + (size_t)ln.b0 * (f.fnet_hidden / 32) * 64;
+        v.zc = w.zc + (size_t)ln.b0 * 32 * f.fnet_hidden; v.hc = w.hc + (size_t)ln.b0 * 32 * f.fnet_inter;
+        v.vc = w.vc + (size_t)ln.b0 * 32 * f.fnet_hidden;
         v.gpart = w.gpart + w.gpart_per_sample * ln.b0;
         return run_fnet(c, packed, tables, v, at(w.xd[L - 1], act_bytes(L - 1), ln.b0), ln.n, S, ln.st);
     }));

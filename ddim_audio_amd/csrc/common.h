@@ -170,6 +170,25 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }
 
+// Sum over aligned groups of 8 or 16 adjacent lanes by DPP (quad swaps, then the half-row / row mirrors): four VALU
+// instructions instead of ds_bpermute round trips; every lane of a group ends with the same bits (each step adds two values
+// that are uniform over the sub-groups it joins).  G = 2: the lane pair (l, l + 32).
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+    static_assert(G == 2 || G == 8 || G == 16, "lane group");
+    if constexpr (G == 2) {
+        return v + __shfl_xor(v, 32, 64);
+    } else {
+        v += dpp_mov_f<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_mov_f<0x4E>(v);   // quad_perm [2,3,0,1]
+        v += dpp_mov_f<0x141>(v);  // row_half_mirror
+        if constexpr (G == 16) v += dpp_mov_f<0x140>(v);  // row_mirror
+        return v;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

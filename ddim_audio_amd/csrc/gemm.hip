@@ -369,7 +369,7 @@ struct MixSmem {
 __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__ dft_hidden /*[2hid][hid]*/,
                                                        const float* __restrict__ dft_seq /*[S][2S]*/,
                                                        const float* __restrict__ X /*[B][S][hid]*/, float* __restrict__ Z, int S,
-                                                       int hid) {
+                                                       int hid, float* __restrict__ zc, float* __restrict__ zstats) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     float* const part = (float*)sm;                            // [4 K-quarters][32 rows][33]
     float* const dsl = part + 4 * MIX_ROWS * 33;               // dft_seq copy [S][2S]
@@ -438,20 +438,31 @@ __global__ void __launch_bounds__(256) fnet_mix_kernel(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int sp = s0 + 16 * u;
-        if (sp >= S) break;
+        if (sp >= S) break;  // (whole 16-lane groups, and S % 8 == 0: whole waves)
         const float* dr = dsl + (size_t)sp * 2 * S;
         float a = 0.f;
         for (int s2 = 0; s2 < S; ++s2) a = fmaf(dr[s2], uc[s2], a);
         for (int s2 = 0; s2 < S; ++s2) a = fmaf(dr[S + s2], us[s2], a);
         const size_t o = ((size_t)b * S + sp) * hid + blockIdx.x * (MIX_ROWS / 2) + j;
-        Z[o] = a + xres[u];
+        const float z = a + xres[u];
+        if (Z) Z[o] = z;
+        if (zc) {  // (uniform) the chunk-major copy and the LayerNorm statistics of row sp over this workgroup's 16 features
+            const int k = blockIdx.x * (MIX_ROWS / 2) + j;
+            zc[(size_t)b * 32 * hid + ((size_t)(k / 4) * 32 + sp) * 4 + k % 4] = z;
+            const float sm = group_sum<16>(z);
+            const float d = z - sm * (1.0f / 16.0f);
+            const float m2 = group_sum<16>(d * d);
+            const int p = blockIdx.x;  // part = column block; [B][parts / 2][32 rows][2 x (sum, m2)]
+            if (j == 0) *(float2*)(zstats + (size_t)b * gridDim.x * 64 + ((size_t)(p / 2) * 32 + sp) * 4 + (p % 2) * 2) = make_float2(sm, m2);
+        }
     }
 }
 bool fnet_mix_supported(int S, int hid) { return S >= 8 && S <= 32 && S % 8 == 0 && hid % 512 == 0; }
 hipError_t fnet_mix_launch(const float* dft_hidden, const float* dft_seq, const float* X, float* Z, int B, int S, int hid,
-                           hipStream_t s) {
-    if (!fnet_mix_supported(S, hid)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fnet_mix_kernel, dim3(2 * hid / MIX_ROWS, B), dim3(256), MixSmem::bytes(S), s, dft_hidden, dft_seq, X, Z, S, hid);
+                           hipStream_t s, float* zc, float* zstats) {
+    if (!fnet_mix_supported(S, hid) || (zc == nullptr) != (zstats == nullptr) || (!Z && !zc)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fnet_mix_kernel, dim3(2 * hid / MIX_ROWS, B), dim3(256), MixSmem::bytes(S), s, dft_hidden, dft_seq, X, Z, S, hid,
+                       zc, zstats);
     return hipGetLastError();
 }
 

@@ -69,8 +69,35 @@ hipError_t gemm_launch(GemmArgs g, hipStream_t s);
 int gemm_pick_splitk(int M, int N, int K, int batch, int bf16);
 // Z[b] = Re(FFT2(X[b])) + X[b] in one launch (gemm.hip); dft_hidden [2hid][hid] interleaved cos/sin rows, dft_seq [S][2S]
 bool fnet_mix_supported(int S, int hid);
+// zc / zstats (nullable, together): ALSO write Z chunk-major ([B][hid/4][32 rows][4], fnet_dense.hip) and, per row and
+// workgroup column block (16 features), the pair (sum, centred sum of squares) of Z as [B][hid/32][32 rows][2 x 2] -- the
+// LayerNorm statistics of the rows for fnet_dense_kernel; Z itself (row-major) may then be null
 hipError_t fnet_mix_launch(const float* dft_hidden, const float* dft_seq, const float* X, float* Z, int B, int S, int hid,
-                           hipStream_t s);
+                           hipStream_t s, float* zc = nullptr, float* zstats = nullptr);
+
+// ---- dense layers of the FNet at S <= 32 without split-K workspace / LayerNorm launches (fnet_dense.hip) ----------------
+// Layouts: "chunk-major" = [sample][k / 4][32 rows][4 fp32] (bf16: [k / 8][32][8]); statistics [sample][part / 2][32][2 x 2].
+struct FnetDenseArgs {
+    const void* W;         // FRAGMENT order (fnet_fold_launch); bf16 when the launch is bf16, else fp32
+    const float* bias;     // [N]
+    const void* X;         // tokens: row-major fp32 [B*S][K], or chunk-major (x_chunk) fp32 / bf16 (x_bf16)
+    const float* xstats;   // non-null: the operand is (x - mean_row) * rstd_row, from xnp parts of xn elements each
+    int xnp, xn;
+    void* out;             // row-major fp32 [B*S][N], or chunk-major (out_chunk) fp32 / bf16 (out_bf16)
+    int x_chunk, x_bf16, out_chunk, out_bf16;
+    int act;               // 1: gelu_new
+    const float* R;        // non-null (chunk-major fp32): + LayerNorm(R)[row][n] * rgamma[n] + rbeta[n], statistics rstats
+    const float* rstats; const float* rgamma; const float* rbeta;
+    int rnp, rn;
+    float* ostats;         // nullable: row statistics of `out` as written, gridDim.x parts of 32 or 64 features
+    float eps;
+    int S, K, N;
+};
+bool fnet_dense_supported(int S, int K, int N);
+hipError_t fnet_dense_launch(const FnetDenseArgs& a, int B, int bf16, hipStream_t s);
+// Wf = W * diag(gamma) (gamma null: W) in MFMA fragment order, optionally rounded to bf16; bf = bias + W * beta (beta null: not written)
+hipError_t fnet_fold_launch(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, int wf_bf16,
+                            float* bf, int N, int K, hipStream_t s);
 // out = LayerNorm(A*B^T + bias + resid) * gamma + beta (rows of N <= 2048), GEMM via the partial workspace
 hipError_t gemm_ln_launch(GemmArgs g, const float* gamma, const float* beta, float eps, float* out, hipStream_t s);
 

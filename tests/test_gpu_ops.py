@@ -197,6 +197,50 @@ def test_fnet_fwd_golden(golden, act, fnet, mx, rms, s):
     assert e_mx <= mx and e_rms <= rms, (act, fnet, s, e_mx, e_rms)
 
 
+@pytest.mark.parametrize("act,fnet,mx,rms", [("FloatTensor", "FloatTensor", 1e-4, 2e-5), ("BFloat16Tensor", "FloatTensor", 2e-2, 4e-3),
+                                            ("BFloat16Tensor", "BFloat16Tensor", 6e-2, 1.2e-2)])
+@pytest.mark.parametrize("s", [8, 16, 24, 32])
+def test_fnet_dense_path_vs_oracle_and_batch_independence(act, fnet, mx, rms, s):
+    """S <= 32 runs the FNet without split-K workspaces and LayerNorm launches (csrc/fnet_dense.hip: row statistics handed
+    from producer to consumer, gamma / beta folded into packed weights, waves of a workgroup splitting K): every supported
+    sequence length, three samples at once, against ``ref_cpu.transformer_module`` (models/diffusion.py:148-167); the middle
+    sample alone must reproduce its rows of the batch bit for bit (per-sample workgroups, fixed summation orders)."""
+    import ctypes
+    from oracle import ref_cpu
+    lib = _lib.load()
+    m = _fnet_model(act, fnet)
+    dev = G.dev()
+    t_len = s * 32
+    lib2 = m._ensure_handle()
+    with torch.cuda.device(dev):
+        m._ensure_packed(lib2, dev)
+        pe, dh, ds = m._ensure_tables(t_len, dev)
+    tok = synth.gaussian(f"fnet.dense.x{s}", (3, s, 2048))
+    tb = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr())
+
+    def run(tk):
+        n = tk.shape[0]
+        x = tk.view(n, s, 256, 8).permute(0, 1, 3, 2).contiguous().to(dev, m._act_dtype)
+        ws = torch.empty(int(lib.ddimx_workspace_bytes(m._handle, n, t_len)), dtype=torch.uint8, device=dev)
+        out = torch.full((n * s, 2048), float("nan"), device=dev)
+        _lib.check(lib.ddimx_fnet_fwd(m._handle, _lib.ptr(m._packed), ctypes.byref(tb), _lib.ptr(ws), ws.numel(), _lib.ptr(x), _lib.ptr(out),
+                                      n, t_len, _lib.stream()))
+        return out.cpu().view(n, s, 8, 256).permute(0, 1, 3, 2).reshape(n, s, 2048)
+
+    y = run(tok)
+    kw = m.config.transformers.kwargs
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items() if k.startswith("transformer.")}
+    with torch.no_grad():
+        want = ref_cpu.transformer_module(sd, tok, kw.num_hidden_layers, kw.layer_norm_eps).double().reshape(-1)
+    got = y.double().reshape(-1)
+    assert torch.isfinite(got).all()
+    sdv = float(want.std())
+    e_mx, e_rms = float((got - want).abs().max()) / sdv, float((got - want).square().mean().sqrt()) / sdv
+    print(f"[fnet_dense {act}/{fnet} S={s}] max {e_mx:.2e} rms {e_rms:.2e} of std")
+    assert e_mx <= mx and e_rms <= rms, (act, fnet, s, e_mx, e_rms)
+    assert torch.equal(run(tok[1:2])[0], y[1]), "a sample's FNet output depends on its batch neighbours"
+
+
 # ---- edge convolutions as single ops -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("cin,c0,hw,b", [(2, 32, (40, 256), 2), (2, 32, (7, 24), 3), (2, 64, (9, 16), 2)])
