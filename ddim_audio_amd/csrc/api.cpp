@@ -155,7 +155,7 @@ struct ddimx_ctx {
     // second copies for fnet_dense_kernel (fnet_dense.hip; offsets into the packed buffer, 0 = none): the first FFN matrix with
     // the preceding LayerNorm's gamma folded in (+ the bias with its beta), compute_out likewise with the last layer's output
     // LayerNorm; all of them in MFMA fragment order and -- bf16 FNet -- pre-rounded to bf16
-    struct FX { size_t w1f, b1f, w2c; };
+    struct FX { size_t w1f, b1f, w2c, tab, bc; };  // tab / bc: the layer's hidden-DFT table with the PREVIOUS layer's output LayerNorm folded in
     std::vector<FX> fx;
     size_t fx_proj = 0, fx_coutf = 0, fx_coutb = 0;
     bool fx_on = false;
@@ -311,6 +311,8 @@ static int build_plan(ddimx_ctx* c) {
             x.w1f = take((size_t)inter * hid * wes);
             x.b1f = take((size_t)inter * 4);
             x.w2c = take((size_t)hid * inter * wes);
+            x.tab = take((size_t)2 * hid * hid * 4);
+            x.bc = take((size_t)hid * 4);
             c->fx.push_back(x);
         }
         c->fx_proj = take((size_t)hid * width * wes);
@@ -911,23 +913,29 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     if (c->fx_on && knobs().fnet_dense != 0 && knobs().fnet_mix != 0 && fnet_mix_supported(S, hid) &&
         fnet_dense_supported(S, hid, inter) && fnet_dense_supported(S, inter, hid) && fnet_dense_supported(S, width, hid) &&
         fnet_dense_supported(S, hid, width)) {
-        // Three or four launches per layer instead of six (fnet_dense.hip): the Fourier mixing also emits the row statistics of
-        // its output; the first FFN matrix normalises its operand from them (gamma / beta folded into the packed weights) and
-        // applies bias + gelu_new; the second adds bias and the recomputed LayerNorm(Z) residual; the output LayerNorm keeps a
-        // launch, except the last one, which compute_out absorbs the same way.
+        // Three launches per layer instead of six (fnet_dense.hip): the Fourier mixing normalises its input rows on the fly (the
+        // previous layer's output LayerNorm: statistics from that layer's last kernel, gamma folded into a per-layer DFT table)
+        // and emits the row statistics of its output; the first FFN matrix normalises its operand from them (gamma / beta folded
+        // into the packed weights) and applies bias + gelu_new; the second adds bias and the recomputed LayerNorm(Z) residual
+        // and emits the statistics of ITS output; compute_out absorbs the last output LayerNorm the same way.
         const char* pk = (const char*)packed;
         const int npz = hid / 16, npv = hid / 32;
         FnetDenseArgs d;
         memset(&d, 0, sizeof(d));
         d.eps = eps; d.S = S;
-        d.W = pk + c->fx_proj; d.bias = pf(c, packed, c->proj_b); d.X = w.ln0; d.out = w.X; d.K = width; d.N = hid;
+        d.W = pk + c->fx_proj; d.bias = pf(c, packed, c->proj_b); d.X = w.ln0; d.out = w.vc; d.out_chunk = 1; d.K = width; d.N = hid;
         HIPCHK(fnet_dense_launch(d, B, bf, s));
-        float* cur = w.X;
         for (int i = 0; i < f.fnet_layers; ++i) {
             const ddimx_ctx::FL& L = c->fl[i];
             const ddimx_ctx::FX& X = c->fx[i];
-            const bool last = i == f.fnet_layers - 1;
-            HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, cur, nullptr, B, S, hid, s, w.zc, w.pz));
+            FnetMixArgs m;
+            memset(&m, 0, sizeof(m));
+            m.tab = (const float*)(pk + X.tab); m.dft_seq = tb->dft_seq; m.V = w.vc; m.zc = w.zc; m.zstats = w.pz; m.eps = eps; m.S = S; m.hid = hid;
+            if (i > 0) {
+                m.vstats = w.pv; m.gamma = pf(c, packed, c->fl[i - 1].ln2_w); m.beta = pf(c, packed, c->fl[i - 1].ln2_b);
+                m.bc = (const float*)(pk + X.bc);
+            }
+            HIPCHK(fnet_mix2_launch(m, B, s));
             memset(&d, 0, sizeof(d));
             d.eps = eps; d.S = S;
             d.W = pk + X.w1f; d.bias = (const float*)(pk + X.b1f); d.X = w.zc; d.x_chunk = 1; d.xstats = w.pz; d.xnp = npz; d.xn = 16;
@@ -936,12 +944,9 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
             memset(&d, 0, sizeof(d));
             d.eps = eps; d.S = S;
             d.W = pk + X.w2c; d.bias = pf(c, packed, L.b2); d.X = w.hc; d.x_chunk = 1; d.x_bf16 = bf; d.K = inter; d.N = hid;
-            d.out = last ? w.vc : w.Y; d.out_chunk = last;
+            d.out = w.vc; d.out_chunk = 1; d.ostats = w.pv;
             d.R = w.zc; d.rstats = w.pz; d.rgamma = pf(c, packed, L.ln1_w); d.rbeta = pf(c, packed, L.ln1_b); d.rnp = npz; d.rn = 16;
-            d.ostats = last ? w.pv : nullptr;
             HIPCHK(fnet_dense_launch(d, B, bf, s));
-            if (!last)
-                HIPCHK(layernorm_launch(DT_F32, w.Y, nullptr, 1, pf(c, packed, L.ln2_w), pf(c, packed, L.ln2_b), eps, cur, M, hid, s));
         }
         memset(&d, 0, sizeof(d));
         d.eps = eps; d.S = S;
@@ -1074,6 +1079,11 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
             HIPCHK(fnet_fold_launch(pf(c, packed, L.w1), pf(c, packed, L.ln1_w), pf(c, packed, L.ln1_b), pf(c, packed, L.b1),
                                     pk + x.w1f, bf, (float*)(pk + x.b1f), inter, hid, s));
             HIPCHK(fnet_fold_launch(pf(c, packed, L.w2), nullptr, nullptr, nullptr, pk + x.w2c, bf, nullptr, hid, inter, s));
+            if (i == 0)
+                HIPCHK(fnet_table_launch(nullptr, nullptr, (float*)(pk + x.tab), nullptr, hid, s));
+            else
+                HIPCHK(fnet_table_launch(pf(c, packed, c->fl[i - 1].ln2_w), pf(c, packed, c->fl[i - 1].ln2_b), (float*)(pk + x.tab),
+                                         (float*)(pk + x.bc), hid, s));
         }
         HIPCHK(fnet_fold_launch(pf(c, packed, c->proj_w), nullptr, nullptr, nullptr, pk + c->fx_proj, bf, nullptr, hid, width, s));
         const ddimx_ctx::FL& LL = c->fl[f.fnet_layers - 1];

@@ -349,6 +349,180 @@ hipError_t fnet_dense_launch(const FnetDenseArgs& a, int B, int bf16, hipStream_
 }
 #endif
 
+// ---- Fourier mixing of the path:  Z = Re(FFT2(X)) + X with X = LayerNorm(V) taken on the fly ------------------------------------
+// fnet_mix_kernel (gemm.hip) restated for the layouts above, absorbing the previous layer's output LayerNorm (one launch less per
+// layer).  With X = N diag(gamma) + 1 beta^T (N = the normalised rows of V):
+//   X D_H^T = N (D_H diag(gamma))^T + 1 (D_H beta)^T        -> the hidden DFT runs on N against a PER-LAYER table with gamma folded
+//                                                              in (fragment order, built at pack time by fnet_table_kernel);
+//   the constant rows (D_H beta) survive the sequence DFT only at s' = 0 (sum_s cos(2 pi s s'/S) = S delta(s'), the sine sums
+//   vanish): S * bc[j] is added to row 0, bc = C_H beta (pack time);
+//   the residual X[s'][j] = N[s'][j] gamma[j] + beta[j] is formed per output element from V and the row statistics.
+// Stage 1: A = 32 table rows in fragment order (one contiguous KiB per wave load), B = V chunk-major, normalised in registers.
+// Stage 2 as fnet_mix_kernel; Z leaves chunk-major with its row statistics.  NORM = false: X = V as is (layer 0: the projection).
+struct FnetMixSmem {
+    static size_t bytes(int S) { return (size_t)(4 * 32 * 33 + S * 2 * S) * 4; }
+};
+template <bool NORM>
+__global__ void __launch_bounds__(256) fnet_mix2_kernel(const FnetMixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    float* const part = (float*)sm;        // [4 K-quarters][32 rows][33]
+    float* const dsl = part + 4 * 32 * 33;  // dft_seq copy [S][2S]
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int S = a.S, hid = a.hid, b = blockIdx.y;
+    const bool tvalid = l31 < S;
+    const int ngroups = hid / 4 / 8, g_first = kq * ngroups;  // 8-k groups of this wave's K quarter
+    const float* vb = a.V + (size_t)b * 32 * hid;
+    // ---- stage-2 operands of this thread: output frequency j, rows s0 + 16 u
+    const int j = tid & 15, s0 = tid >> 4, k = blockIdx.x * 16 + j;
+    float dpre[8], xres[2], rs[2], rm[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = tid + u * 256;
+        dpre[u] = a.dft_seq[i < S * 2 * S ? i : 0];
+    }
+    float gk = 1.f, bk = 0.f, bck = 0.f;
+    if constexpr (NORM) { gk = a.gamma[k]; bk = a.beta[k]; bck = a.bc[k]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int sp = s0 + 16 * u;  // (< 32: a valid address in the block whatever S)
+        xres[u] = vb[((size_t)(k / 4) * 32 + sp) * 4 + k % 4];
+        if constexpr (NORM) {  // part j of row sp (16 parts of hid / 16 elements)
+            const float2 v = *(const float2*)(a.vstats + (size_t)b * 16 * 64 + ((size_t)(j / 2) * 32 + sp) * 4 + (j % 2) * 2);
+            rs[u] = v.x; rm[u] = v.y;
+        }
+    }
+    // ---- statistics of the MFMA operand's row (lane (r, h): 8 of the 16 parts)
+    float xps[8], xpm[8];
+    if constexpr (NORM) {
+        const float* sp = a.vstats + (size_t)b * 16 * 64 + ((size_t)h * 4 * 32 + l31) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *(const float4*)(sp + (size_t)q * 128);
+            xps[2 * q] = v.x; xpm[2 * q] = v.y; xps[2 * q + 1] = v.z; xpm[2 * q + 1] = v.w;
+        }
+    }
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const f32x4_t* wp = (const f32x4_t*)a.tab + ((size_t)blockIdx.x * (hid / 8) + g_first) * 64 + lane;
+    const char* xp = (const char*)(vb + ((size_t)(2 * g_first + h) * 32 + l31) * 4);
+    constexpr int GP = 16;
+    float xa = 1.f, xc = 0.f;
+    for (int g0 = 0; g0 < ngroups; g0 += GP) {
+        f32x4_t ra[GP], rb[GP];
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+            ra[g] = wp[(size_t)(g0 + g) * 64];
+            rb[g] = *(const f32x4_t*)(xp + (size_t)(g0 + g) * 2 * 32 * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NORM) {
+            if (g0 == 0) {
+                float mean, rstd;
+                fold_row_stats<2, 8>(xps, xpm, 8, (float)(hid / 16), (float)hid, a.eps, &mean, &rstd);
+                xa = rstd;
+                xc = -mean * rstd;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[g][i] = tvalid ? fmaf(rb[g][i], xa, xc) : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][0], rb[g][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][1], rb[g][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][2], rb[g][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][3], rb[g][3], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = tid + u * 256;
+        if (i < S * 2 * S) dsl[i] = dpre[u];
+    }
+    // this wave's partial Ut[32 table rows][tokens] -> its LDS slab (D layout: row = (r & 3) + 8 (r >> 2) + 4 h, col = l31)
+    float* const mine = part + kq * 32 * 33;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
+    __syncthreads();
+    for (int i = tid; i < 32 * 32; i += 256) {  // fixed-order sum of the four K quarters, in place in slab 0
+        const int o = (i >> 5) * 33 + (i & 31);
+        part[o] = ((part[o] + part[32 * 33 + o]) + part[2 * 32 * 33 + o]) + part[3 * 32 * 33 + o];
+    }
+    __syncthreads();
+    const float* uc = part + (2 * j) * 33;
+    const float* us = part + (2 * j + 1) * 33;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int sp = s0 + 16 * u;
+        if (sp >= S) break;  // (whole 16-lane groups, and S % 8 == 0: whole waves)
+        const float* dr = dsl + (size_t)sp * 2 * S;
+        float t = 0.f;
+        for (int s2 = 0; s2 < S; ++s2) t = fmaf(dr[s2], uc[s2], t);
+        for (int s2 = 0; s2 < S; ++s2) t = fmaf(dr[S + s2], us[s2], t);
+        float x = xres[u];
+        if constexpr (NORM) {
+            const float n_part = (float)(hid / 16);
+            const float mean = group_sum<16>(rs[u]) / (float)hid;
+            const float d = rs[u] / n_part - mean;
+            const float m2 = group_sum<16>(fmaf(n_part * d, d, rm[u]));
+            const float rstd = 1.0f / sqrtf(m2 / (float)hid + a.eps);
+            x = fmaf((x - mean) * rstd, gk, bk);
+            if (sp == 0) t = fmaf((float)S, bck, t);
+        }
+        const float z = t + x;
+        a.zc[(size_t)b * 32 * hid + ((size_t)(k / 4) * 32 + sp) * 4 + k % 4] = z;
+        const float sm2 = group_sum<16>(z);
+        const float dz = z - sm2 * (1.0f / 16.0f);
+        const float m2z = group_sum<16>(dz * dz);
+        const int p = blockIdx.x;
+        if (j == 0) *(float2*)(a.zstats + (size_t)b * gridDim.x * 64 + ((size_t)(p / 2) * 32 + sp) * 4 + (p % 2) * 2) = make_float2(sm2, m2z);
+    }
+}
+#ifndef DDIMX_FD_STAMP
+hipError_t fnet_mix2_launch(const FnetMixArgs& a, int B, hipStream_t s) {
+    if (a.hid != 512 || a.S < 8 || a.S > 32 || a.S % 8) return hipErrorInvalidValue;  // (16 statistics parts, one pass of 16 groups)
+    const dim3 grid(a.hid / 16, B), block(256);
+    if (a.vstats)
+        hipLaunchKernelGGL(fnet_mix2_kernel<true>, grid, block, FnetMixSmem::bytes(a.S), s, a);
+    else
+        hipLaunchKernelGGL(fnet_mix2_kernel<false>, grid, block, FnetMixSmem::bytes(a.S), s, a);
+    return hipGetLastError();
+}
+#endif
+
+// Per-layer hidden-DFT table in fragment order: row 2j = cos(2 pi j h / H) gamma[h], row 2j + 1 = sin(2 pi j h / H) gamma[h]
+// (gamma null: 1), as [row / 32][h / 8][lane = 32 hh + row % 32][4], h = 8 g + 4 hh + i (argument reduced exactly mod H, fp64
+// trigonometry rounded once, like model.py::_dft_tables); bc[j] = sum_h cos(2 pi j h / H) beta[h] (beta null: not written),
+// fixed-order fp64 tree.  One workgroup per table row.
+__global__ void __launch_bounds__(256) fnet_table_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ tab, float* __restrict__ bc, int H) {
+    __shared__ double red[4];
+    const int row = blockIdx.x, jf = row >> 1, p = row & 1, tid = threadIdx.x;
+    double s = 0.0;
+    for (int hcol = tid; hcol < H; hcol += 256) {
+        const int m = (int)(((long long)jf * hcol) % H);
+        const double ang = 2.0 * 3.14159265358979323846 * (double)m / (double)H;
+        const double cv = cos(ang), tv = p ? sin(ang) : cv;
+        const int g = hcol / 8, hh = (hcol % 8) / 4, i = hcol % 4;
+        tab[(((size_t)(row / 32) * (H / 8) + g) * 64 + hh * 32 + row % 32) * 4 + i] = (float)tv * (gamma ? gamma[hcol] : 1.0f);
+        if (beta && p == 0) s += (double)(float)cv * (double)beta[hcol];
+    }
+    if (!beta || p) return;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) bc[jf] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+hipError_t fnet_table_launch(const float* gamma, const float* beta, float* tab, float* bc, int H, hipStream_t s) {
+    if (H % 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fnet_table_kernel, dim3(2 * H), dim3(256), 0, s, gamma, beta, tab, bc, H);
+    return hipGetLastError();
+}
+
 // ---- weight packing for the path ------------------------------------------------------------------------------------------
 // Wf = W diag(gamma) (gamma null: W) in FRAGMENT order -- bf16: [n / 32][k / 16][lane = 32 h + n % 32][8], k = 16 g + 8 h + i;
 // fp32: [n / 32][k / 8][lane][4], k = 8 g + 4 h + i --; bf[n] = bias[n] + sum_k W[n][k] beta[k] (beta null: not written).

@@ -93,6 +93,19 @@ struct FnetDenseArgs {
     float eps;
     int S, K, N;
 };
+// Fourier mixing over those layouts with the previous layer's output LayerNorm taken on the fly (fnet_dense.hip)
+struct FnetMixArgs {
+    const float* tab;      // hidden-DFT table of this layer, gamma folded in, fragment order (fnet_table_launch)
+    const float* dft_seq;  // [S][2S] = [cos | -sin]
+    const float* V;        // chunk-major fp32 input rows
+    const float* vstats;   // their statistics (16 parts of hid / 16); null: the rows are used as they are
+    const float* gamma; const float* beta; const float* bc;  // LayerNorm affine and C_H beta (with vstats)
+    float* zc; float* zstats;  // chunk-major Z and its row statistics (hid / 16 parts of 16)
+    float eps;
+    int S, hid;
+};
+hipError_t fnet_mix2_launch(const FnetMixArgs& a, int B, hipStream_t s);
+hipError_t fnet_table_launch(const float* gamma, const float* beta, float* tab, float* bc, int H, hipStream_t s);
 bool fnet_dense_supported(int S, int K, int N);
 hipError_t fnet_dense_launch(const FnetDenseArgs& a, int B, int bf16, hipStream_t s);
 // Wf = W * diag(gamma) (gamma null: W) in MFMA fragment order, optionally rounded to bf16; bf = bias + W * beta (beta null: not written)

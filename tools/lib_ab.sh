@@ -16,7 +16,7 @@ done
 cd /tmp && export TMPDIR=/tmp
 for tag in base new; do
   if [ $tag = base ]; then export DDIMX_LIB=$R/ddim_audio_amd/libddimx_base.so; else export DDIMX_LIB=$R/ddim_audio_amd/libddimx.so; fi
-  DDIMX_FORK_MASK=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$tag -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-train-leg > /tmp/pf_$tag.log 2>&1
+  rm -rf /tmp/pf_$tag; DDIMX_FORK_MASK=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$tag -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-train-leg > /tmp/pf_$tag.log 2>&1
   cp $(find /tmp/pf_$tag -name "*kernel_stats.csv" | head -n1) $R/$out/kernel_stats_$tag.csv
 done
 cd $R; tail -n 20 $out/ops_*.txt $out/bench*.txt
