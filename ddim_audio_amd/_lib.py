@@ -80,6 +80,9 @@ _SIGS = {
     "ddimx_pack_frag_from_taps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddimx_upsample_add_wreg_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                             c_void_p]),
+    "ddimx_conv3x3_ws_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddimx_conv3x3_ws_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "ddimx_conv3x3_wreg_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddimx_conv3x3_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libddimx.so")
 SOURCES = ["api.cpp", "kernels.hip", "gemm.hip", "fnet_dense.hip", "conv_inst_bf16_c3.hip", "conv_inst_bf16_du.hip",
-           "conv_inst_f32_c3.hip", "conv_inst_f32_du.hip", "conv_inst_bf16_c3b.hip", "conv_inst_bf16_fold.hip", "conv_inst_bf16_wreg.hip", "conv_inst_f32_c3b.hip", "train_kernels.hip", "wgrad_inst_bf16.hip", "wgrad_inst_f32.hip"]
+           "conv_inst_f32_c3.hip", "conv_inst_f32_du.hip", "conv_inst_bf16_c3b.hip", "conv_inst_bf16_fold.hip", "conv_inst_bf16_wreg.hip", "conv_inst_bf16_ws.hip", "conv_inst_f32_c3b.hip", "train_kernels.hip", "wgrad_inst_bf16.hip", "wgrad_inst_f32.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
 
 

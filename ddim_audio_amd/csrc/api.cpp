@@ -16,13 +16,13 @@
 #include "train_kernels.h"
 #include "wgrad_mfma.h"
 #include "conv_fold.h"
-#include "conv_wreg.h"
+#include "conv_ws.h"
 
 namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int fnet_dense;
+    int fnet_dense, conv_ws;
     int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold, conv_wreg;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -33,6 +33,7 @@ struct Knobs {
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
         fnet_dense = geti("DDIMX_FNET_DENSE", 1);
+        conv_ws = geti("DDIMX_CONV_WS", 0);  // opt-in: the wave-specialised kernel (conv_ws.h) -- correct and tested, but no faster
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
         two_tiles = geti("DDIMX_TWO_TILES", 0);
         conv_stagger = geti("DDIMX_CONV_STAGGER", 0);
@@ -193,7 +194,8 @@ static RBW add_rb(ddimx_ctx* c, const std::string& p, int C, int k) {
     r.w1 = add_spec(c, p + "conv.1.weight", PK_CONV, C, C, k, k);
     r.bias1 = add_spec(c, p + "conv.1.bias", PK_COPY, C);
     WregGeom wg;
-    if (c->dtype == DT_BF16 && k == 3 && wreg_geometry(CONV3, C, C, &wg) == hipSuccess) {  // second copy in MFMA fragment order
+    WsGeom wsg;
+    if (c->dtype == DT_BF16 && k == 3 && (wreg_geometry(CONV3, C, C, &wg) == hipSuccess || ws_geometry(C, &wsg) == hipSuccess)) {  // second copy in MFMA fragment order
         c->frag_off.resize(c->specs.size(), 0);
         for (int i : {r.w0, r.w1}) {
             c->frag_off[i] = c->packed_bytes;
@@ -478,6 +480,7 @@ struct ConvCall {
     GnIn gn = {};             // gn.stats set: the input's GroupNorm is finished inside the kernel (in_scale / in_shift unused)
     bool groups = false;      // statistics partials in group format (gn_fused.h)
     const void* wf = nullptr; // the same weights in MFMA fragment order (conv_wreg.h), if the caller has them
+    int kernel_pref = 0;      // 0: the walk's choice; 1: never the wave-specialised kernel (conv_ws.h); 2: only it (per-op exports)
     bool force_fold = false;  // ddimx_conv3x3_fold_fwd: take the folded-affine kernel whatever the DDIMX_CONV_FOLD default
 };
 
@@ -488,7 +491,7 @@ struct BatchPlanScope {
     ~BatchPlanScope() { g_batch_plan = false; }
 };
 // Plan of one conv launch: tile configuration and the persistent-workgroup split.
-struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; bool fold, wreg; };
+struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; bool fold, wreg, ws; };
 // The folded-affine kernel (conv_fold.h) takes a 3x3 conv whose input transform is a plain per-channel affine (the block's second
 // conv in the inference walk) when a configuration exists for the width and the image is a whole number of its tiles.  The
 // choice depends on the sample's size only (never on the batch).
@@ -509,10 +512,33 @@ static bool wreg_eligible(const ConvCall& q, WregGeom* wg) {
     const int sxy = q.mode == DOWN4 ? 2 : 1;
     return q.Hin % (wg->th * sxy) == 0 && q.Win % (wg->tw * sxy) == 0;
 }
+// The wave-specialised kernel (conv_ws.h) takes the Residual_Block convs of the inference walk at the widths it is instantiated
+// for, under the same conditions (fragment-order weights, whole tiles; sample size only, never the batch).
+static bool ws_eligible(const ConvCall& q, WsGeom* wg) {
+    if (q.kernel_pref == 1 || !(knobs().conv_ws || q.kernel_pref == 2)) return false;
+    if (!q.wf || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.act > 1 || q.aux || q.bwd_mode || q.skip || q.batch_plan || g_batch_plan)
+        return false;
+    if (q.xf != XF_NONE && q.xf != XF_AFFINE && q.xf != XF_AFFINE_SILU) return false;
+    if (ws_geometry(q.cin, wg) != hipSuccess) return false;
+    return q.Hin % wg->th == 0 && q.Win % wg->tw == 0;
+}
 static int conv_plan(const ConvCall& q, ConvPlan* p) {
     ConvGeom& g = p->g;
     p->fold = false;
     p->wreg = false;
+    p->ws = false;
+    WsGeom wsg;
+    if (ws_eligible(q, &wsg)) {
+        p->ws = true;
+        p->Hv = q.Hin; p->Wv = q.Win; p->var = 0;
+        g.th = wsg.th; g.tw = wsg.tw; g.nb = g.nout = q.cout; g.classes = 1; g.lds_bytes = wsg.lds_bytes; g.nthreads = wsg.nthreads;
+        p->tiles_x = q.Win / wsg.tw;
+        p->tiles_y = q.Hin / wsg.th;
+        p->tiles_per_wg = wsg.tiles_per_wg;
+        p->wgs_per_sample = cdiv(p->tiles_x * p->tiles_y, p->tiles_per_wg);
+        return 0;
+    }
+    if (q.kernel_pref == 2) return fail("conv %d->%d %dx%d: not eligible for the wave-specialised kernel", q.cin, q.cout, q.Hin, q.Win);
     WregGeom wgm;
     if (wreg_eligible(q, &wgm)) {
         p->wreg = true;
@@ -591,19 +617,21 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     ConvPlan pl;
     CHK(conv_plan(q, &pl));
     const ConvGeom& g = pl.g;
-    if (pl.wreg) {
+    if (pl.wreg || pl.ws) {
         WregArgs f;
         memset(&f, 0, sizeof(f));
         f.in = q.in; f.wf = q.wf; f.skip = q.skip; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
         f.in_scale = q.in_scale; f.in_shift = q.in_shift; f.gn = q.gn; f.out = q.out; f.stats = q.stats;
         f.stats_groups_c = q.groups ? q.cout : 0; f.xf = q.xf; f.act = q.act; f.stamps = q.stamps;
+        { static const int dbg = getenv("DDIMX_WS_DBG") ? atoi(getenv("DDIMX_WS_DBG")) : 0; f.dbg = dbg; }
         if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
         if (q.xf != XF_NONE && !q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
         f.B = q.B; f.H = q.Hin; f.W = q.Win;
         f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
         if (nparts) *nparts = f.wgs_per_sample * g.classes * (q.groups ? g.nout / g.nb : 1);
         if (Cs) *Cs = g.nout;
-        HIPCHK(wreg_launch(q.mode, q.cin, g.nout, f, s));
+        if (pl.ws) HIPCHK(ws_launch(q.cin, f, s));
+        else HIPCHK(wreg_launch(q.mode, q.cin, g.nout, f, s));
         return 0;
     }
     if (pl.fold) {
@@ -2042,11 +2070,26 @@ int ddimx_upsample_add_wreg_fwd(int Cin, int Cout, const void* x, const void* w_
     if (!pl.wreg) return fail("ddimx_upsample_add_wreg_fwd: %d->%d %dx%d is not eligible for the register-streamed kernel", Cin, Cout, H, W);
     return run_conv(u, (hipStream_t)stream, nullptr, nullptr);
 }
+int ddimx_conv3x3_ws_fwd(int C, const void* x, const void* w_frag, const float* bias, const float* chan_add, int chan_add_stride,
+                         const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats, int B, int H, int W,
+                         void* stream) {
+    ConvCall k = {DT_BF16, CONV3, C, C, x, nullptr, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
+    k.wf = w_frag;
+    k.kernel_pref = 2;
+    k.stamps = g_debug_stamps;
+    return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
+}
+long long ddimx_conv3x3_ws_stats_floats(int C, int B, int H, int W) {
+    WsGeom g;
+    if (ws_geometry(C, &g) != hipSuccess || H % g.th || W % g.tw) return -1;
+    return (long long)B * cdiv((H / g.th) * (W / g.tw), g.tiles_per_wg) * C * 2;
+}
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats,
                            int B, int H, int W, void* stream) {
     ConvCall k = {DT_BF16, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
     k.wf = w_frag;
+    k.kernel_pref = 1;
     k.stamps = g_debug_stamps;
     ConvPlan pl;
     CHK(conv_plan(k, &pl));

@@ -38,6 +38,7 @@ struct WregArgs {
     int B, H, W;            // the INPUT image (Downsample: the output is H/2 x W/2)
     int tiles_x, tiles_y, tiles_per_wg, wgs_per_sample;  // tiles of the OUTPUT image
     unsigned long long* stamps;  // diagnostic builds only (-DDDIMX_STAMP)
+    int dbg;                     // diagnostic builds only
 };
 
 template <int CIN_, int COUT_, int MODE_, int TH_, int TW_, int WM_, int WN_, int D_, int NS_ = 1>

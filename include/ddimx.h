@@ -223,6 +223,14 @@ int ddimx_downsample_wreg_fwd(int Cin, int Cout, const void* x, const void* w_fr
 int ddimx_pack_frag_from_taps(const void* taps, void* dst, int ntaps, int NOUT, int CIN, void* stream);
 int ddimx_upsample_add_wreg_fwd(int Cin, int Cout, const void* x, const void* w_frag, const float* bias2, const void* skip, void* y,
                                 float* stats, int B, int H, int W, void* stream);
+/* The same two convolutions through the wave-specialised kernel (csrc/conv_ws.h: MFMA waves multiply tile t while loader waves
+ * fetch + transform the halo of tile t + 1 and drain the output of tile t - 1; C = 32 / 64, whole tiles of the configuration);
+ * arguments as ddimx_conv3x3_wreg_fwd without the LDS-layout weights.  stats: per-channel (sum, sumsq) partials
+ * [B][workgroups per sample][C][2], ddimx_conv3x3_ws_stats_floats floats (-1: shape not eligible). */
+int ddimx_conv3x3_ws_fwd(int C, const void* x, const void* w_frag, const float* bias, const float* chan_add, int chan_add_stride,
+                         const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats, int B, int H, int W,
+                         void* stream);
+long long ddimx_conv3x3_ws_stats_floats(int C, int B, int H, int W);
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                            float* stats, int B, int H, int W, void* stream);

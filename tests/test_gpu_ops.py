@@ -378,6 +378,57 @@ def test_wreg_conv_vs_fp32_reference(c, hw, xf):
     assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("xf", [0, 1, 2])
+@pytest.mark.parametrize("c,hw,b", [(32, (16, 32), 2), (32, (48, 64), 2), (32, (16 * 17, 32), 3), (64, (8, 32), 2), (64, (24, 64), 2),
+                                    (64, (8 * 9, 32), 3)])
+def test_ws_conv_vs_fp32_reference(c, hw, b, xf):
+    """Both convs of Residual_Block (models/diffusion.py:46-53) through the wave-specialised kernel (csrc/conv_ws.h): MFMA waves
+    multiply tile t from one halo buffer while loader waves fetch + transform tile t + 1 into the other and drain tile t - 1.
+    Against fp32 torch on the same bf16-rounded operands: one tile, several tiles per workgroup (all four borders, both halo
+    buffers in use), more tiles than one workgroup takes (17 / 9 tile rows: a second, shorter workgroup per sample), three
+    samples; statistics of the values as stored."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    dt = G.BF16
+    h, w = hw
+    dev = G.dev()
+    x = (synth.gaussian(f"ws.x{c}", (b, c, h, w)) * 1.2 + 0.2).bfloat16().float()
+    wt = synth.gaussian(f"ws.w{c}", (c, c, 3, 3)) / (9 * c) ** 0.5
+    bias = synth.gaussian(f"ws.b{c}", (c,)) * 0.3
+    temb = synth.gaussian(f"ws.t{c}", (b, c)) * 0.3
+    scale = synth.gaussian(f"ws.s{c}", (b, c)) * 0.3 + 1.0
+    shift = synth.gaussian(f"ws.h{c}", (b, c)) * 0.5
+    xn = G.to_nhwc(x, dt)
+    wf = torch.empty(9 * c * c, dtype=torch.bfloat16, device=dev)
+    wt_d = wt.to(dev).contiguous()
+    _lib.check(lib.ddimx_pack_conv_frag(_lib.ptr(wt_d), _lib.ptr(wf), c, c, _lib.stream()))
+    y = torch.full_like(xn, float("nan"))
+    nst = int(lib.ddimx_conv3x3_ws_stats_floats(c, b, h, w))
+    assert nst > 0
+    stats = torch.zeros(nst, device=dev)
+    bias_d, temb_d, scale_d, shift_d = bias.to(dev), temb.to(dev), scale.to(dev), shift.to(dev)
+    use_temb = xf == 2
+    _lib.check(lib.ddimx_conv3x3_ws_fwd(c, _lib.ptr(xn), _lib.ptr(wf), None if use_temb else _lib.ptr(bias_d),
+                                        _lib.ptr(temb_d) if use_temb else None, c, _lib.ptr(scale_d), _lib.ptr(shift_d), xf, 1,
+                                        _lib.ptr(y), _lib.ptr(stats), b, h, w, _lib.stream()))
+    torch.cuda.synchronize()
+    got = G.from_nhwc(y, dt)
+    assert torch.isfinite(got).all(), "a pixel was never written"
+    yn = x
+    if xf:
+        yn = x * scale[:, :, None, None] + shift[:, :, None, None]
+        if xf == 2:
+            yn = F.silu(yn)
+    yn = yn.bfloat16().float()  # the kernel rounds the transformed input to bf16 before the MFMAs
+    add = temb[:, :, None, None] if use_temb else bias[None, :, None, None]
+    want = F.silu(F.conv2d(yn, wt.bfloat16().float(), None, padding=1) + add)
+    G.check_close(got, want, dt, f"ws conv C={c} {hw} xf={xf}")
+    st = stats.cpu().view(-1, c, 2).double().sum(0)
+    gs = got.double()
+    assert torch.allclose(st[:, 0], gs.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, 1], gs.square().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("cin,cout,hw", [(32, 64, (32, 64)), (64, 96, (16, 64)), (96, 128, (16, 32)), (128, 192, (16, 32)), (192, 256, (8, 32))])
 def test_wreg_downsample_vs_fp32_reference(cin, cout, hw):
     """Downsample = Conv2d(k4, s2, p1) + bias (models/diffusion.py:70-78) through the register-streamed-weights kernel, as the
