@@ -366,6 +366,9 @@ __global__ void __launch_bounds__(F::NTHREADS, (F::NWAVES + 3) / 4) conv3_ws_ker
 #endif
 #pragma unroll
                 for (int m = 0; m < F::MT; ++m) Mma<T>::run(af, bq[s & 1][m], acc[m]);
+#ifdef DDIMX_STAMP
+                if (!(a.dbg & 4))
+#endif
                 if constexpr (F::D < F::NSTEP) aw[s % F::D] = wfrag((s + F::D) % F::NSTEP);  // wraps into the next tile
                 __builtin_amdgcn_sched_barrier(0);
             }
