@@ -440,7 +440,7 @@ static void carve(const ddimx_ctx* c, char* base, int B, int T, Ws* w) {
     const int S = T >> (L - 1);
     const size_t M = (size_t)B * S;
     const int hid = f.fnet_hidden, inter = f.fnet_inter;
-    w->ln0 = (float*)cv.take(M * c->width * 4);
+    w->ln0 = (float*)cv.take((size_t)B * (S > 32 ? S : 32) * c->width * 4);  // (chunk-major for the dense FNet path: 32 rows per sample)
     w->X = (float*)cv.take(M * hid * 4);
     w->Ut = (float*)cv.take((size_t)B * 2 * hid * S * 4);
     w->Z = (float*)cv.take(M * hid * 4);
@@ -936,11 +936,12 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
     const float eps = f.fnet_ln_eps;
     const int bf = c->fnet_bf16;
+    const bool dense = c->fx_on && knobs().fnet_dense != 0 && knobs().fnet_mix != 0 && fnet_mix_supported(S, hid) &&
+                       fnet_dense_supported(S, hid, inter) && fnet_dense_supported(S, inter, hid) && fnet_dense_supported(S, width, hid) &&
+                       fnet_dense_supported(S, hid, width);
     HIPCHK(layernorm_launch(c->dtype, x, tb->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps, w.ln0, M,
-                            width, s));
-    if (c->fx_on && knobs().fnet_dense != 0 && knobs().fnet_mix != 0 && fnet_mix_supported(S, hid) &&
-        fnet_dense_supported(S, hid, inter) && fnet_dense_supported(S, inter, hid) && fnet_dense_supported(S, width, hid) &&
-        fnet_dense_supported(S, hid, width)) {
+                            width, s, dense ? S : 0));
+    if (dense) {
         // Three launches per layer instead of six (fnet_dense.hip): the Fourier mixing normalises its input rows on the fly (the
         // previous layer's output LayerNorm: statistics from that layer's last kernel, gamma folded into a per-layer DFT table)
         // and emits the row statistics of its output; the first FFN matrix normalises its operand from them (gamma / beta folded
@@ -951,7 +952,7 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
         FnetDenseArgs d;
         memset(&d, 0, sizeof(d));
         d.eps = eps; d.S = S;
-        d.W = pk + c->fx_proj; d.bias = pf(c, packed, c->proj_b); d.X = w.ln0; d.out = w.vc; d.out_chunk = 1; d.K = width; d.N = hid;
+        d.W = pk + c->fx_proj; d.bias = pf(c, packed, c->proj_b); d.X = w.ln0; d.x_chunk = 1; d.out = w.vc; d.out_chunk = 1; d.K = width; d.N = hid;
         HIPCHK(fnet_dense_launch(d, B, bf, s));
         for (int i = 0; i < f.fnet_layers; ++i) {
             const ddimx_ctx::FL& L = c->fl[i];
@@ -1243,7 +1244,7 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     CHK(for_lanes((fork_mask >> 16) & 1u, [&](const Lane& ln) -> int {
         Ws v = w;  // this shard's rows of every token matrix, its share of the split-K scratch
         const size_t rows = (size_t)ln.b0 * S;
-        v.ln0 = w.ln0 + rows * c->width; v.X = w.X + rows * f.fnet_hidden; v.Z = w.Z + rows * f.fnet_hidden;
+        v.ln0 = w.ln0 + (size_t)ln.b0 * (S > 32 ? S : 32) * c->width; v.X = w.X + rows * f.fnet_hidden; v.Z = w.Z + rows * f.fnet_hidden;
         v.Y = w.Y + rows * f.fnet_hidden; v.Hb = w.Hb + rows * f.fnet_inter; v.O = w.O + rows * c->width;
         v.Ut = w.Ut + (size_t)ln.b0 * 2 * f.fnet_hidden * S;
         v.pz = w.pz + (size_t)ln.b0 * (f.fnet_hidden / 16) * 64; v.pv = w.pv + (size_t)ln.b0 * (f.fnet_hidden / 32) * 64;

@@ -332,6 +332,7 @@ hipError_t fnet_dense_launch(const FnetDenseArgs& a, int B, int bf16, hipStream_
             if (a.out_bf16 || xf) return hipErrorInvalidValue;
             if (a.x_bf16) { if (res) DDIMX_FD(1, true, false, 1, 8, 0, 1, 16, true); else DDIMX_FD(1, true, false, 1, 8, 0, 1, 16, false); }
             else if (!a.x_chunk && !res) DDIMX_FD(1, false, false, 1, 8, 0, 0, 8, false);
+            else if (!res) DDIMX_FD(1, false, false, 1, 8, 0, 1, 8, false);  // chunk-major fp32 tokens (the projection)
             else return hipErrorInvalidValue;
         }
     } else {
@@ -360,13 +361,14 @@ hipError_t fnet_dense_launch(const FnetDenseArgs& a, int B, int bf16, hipStream_
 // Stage 1: A = 32 table rows in fragment order (one contiguous KiB per wave load), B = V chunk-major, normalised in registers.
 // Stage 2 as fnet_mix_kernel; Z leaves chunk-major with its row statistics.  NORM = false: X = V as is (layer 0: the projection).
 struct FnetMixSmem {
-    static size_t bytes(int S) { return (size_t)(4 * 32 * 33 + S * 2 * S) * 4; }
+    static size_t bytes(int S) { return (size_t)(4 * 32 * 36 + S * 2 * S) * 4; }
 };
 template <bool NORM>
 __global__ void __launch_bounds__(256) fnet_mix2_kernel(const FnetMixArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    float* const part = (float*)sm;        // [4 K-quarters][32 rows][33]
-    float* const dsl = part + 4 * 32 * 33;  // dft_seq copy [S][2S]
+    constexpr int MP = 36;                 // floats per row of a partial slab (144 B: the sequence DFT reads it 16 bytes at a time)
+    float* const part = (float*)sm;        // [4 K-quarters][32 rows][MP]
+    float* const dsl = part + 4 * 32 * MP;  // dft_seq copy [S][2S]
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int S = a.S, hid = a.hid, b = blockIdx.y;
@@ -444,25 +446,34 @@ __global__ void __launch_bounds__(256) fnet_mix2_kernel(const FnetMixArgs a) {
         if (i < S * 2 * S) dsl[i] = dpre[u];
     }
     // this wave's partial Ut[32 table rows][tokens] -> its LDS slab (D layout: row = (r & 3) + 8 (r >> 2) + 4 h, col = l31)
-    float* const mine = part + kq * 32 * 33;
+    float* const mine = part + kq * 32 * MP;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * MP + l31] = acc[r];
     __syncthreads();
-    for (int i = tid; i < 32 * 32; i += 256) {  // fixed-order sum of the four K quarters, in place in slab 0
-        const int o = (i >> 5) * 33 + (i & 31);
-        part[o] = ((part[o] + part[32 * 33 + o]) + part[2 * 32 * 33 + o]) + part[3 * 32 * 33 + o];
+    {   // fixed-order sum of the four K quarters, in place in slab 0: thread = (row, four tokens)
+        const int o = (tid >> 3) * MP + (tid & 7) * 4;
+        const float4 p0 = *(const float4*)(part + o), p1 = *(const float4*)(part + 32 * MP + o);
+        const float4 p2 = *(const float4*)(part + 2 * 32 * MP + o), p3 = *(const float4*)(part + 3 * 32 * MP + o);
+        *(float4*)(part + o) = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                           ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
     }
     __syncthreads();
-    const float* uc = part + (2 * j) * 33;
-    const float* us = part + (2 * j + 1) * 33;
+    const float* uc = part + (2 * j) * MP;
+    const float* us = part + (2 * j + 1) * MP;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int sp = s0 + 16 * u;
         if (sp >= S) break;  // (whole 16-lane groups, and S % 8 == 0: whole waves)
         const float* dr = dsl + (size_t)sp * 2 * S;
         float t = 0.f;
-        for (int s2 = 0; s2 < S; ++s2) t = fmaf(dr[s2], uc[s2], t);
-        for (int s2 = 0; s2 < S; ++s2) t = fmaf(dr[S + s2], us[s2], t);
+        for (int s4 = 0; s4 < S; s4 += 4) {  // (same order of addition as the scalar loop; S % 8 == 0)
+            const float4 d = *(const float4*)(dr + s4), v = *(const float4*)(uc + s4);
+            t = fmaf(d.x, v.x, t); t = fmaf(d.y, v.y, t); t = fmaf(d.z, v.z, t); t = fmaf(d.w, v.w, t);
+        }
+        for (int s4 = 0; s4 < S; s4 += 4) {
+            const float4 d = *(const float4*)(dr + S + s4), v = *(const float4*)(us + s4);
+            t = fmaf(d.x, v.x, t); t = fmaf(d.y, v.y, t); t = fmaf(d.z, v.z, t); t = fmaf(d.w, v.w, t);
+        }
         float x = xres[u];
         if constexpr (NORM) {
             const float n_part = (float)(hid / 16);

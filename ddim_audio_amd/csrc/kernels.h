@@ -48,8 +48,9 @@ hipError_t temb_gather_launch(const float* table /*[n_timesteps][E]*/, const int
 
 // ---- LayerNorm over rows -----------------------------------------------------------------------------
 // y = LN(x [+ add[(m % add_rows)]]) * gamma + beta;  x is T (dtype) or fp32 (dtype = DT_F32)
+// chunk_rows > 0: y is written chunk-major for fnet_dense_kernel, rows of a sample = chunk_rows (<= 32)
 hipError_t layernorm_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma,
-                            const float* beta, float eps, float* y, int M, int N, hipStream_t s);
+                            const float* beta, float eps, float* y, int M, int N, hipStream_t s, int chunk_rows = 0);
 
 // ---- "NT" GEMM (gemm.hip): C[z][M][N] (+)= A[z][M][K] * B[z][N][K]^T; fp32 or bf16 MFMA, optional split-K ----
 struct GemmArgs {

@@ -865,7 +865,7 @@ template <typename TX>
 __global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x, const float* __restrict__ add,
                                                         int add_rows, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        float* __restrict__ y, int N) {
+                                                        float* __restrict__ y, int N, int chunk_rows) {
     __shared__ float red[4];
     __shared__ float bc;
     const int m = blockIdx.x, tid = threadIdx.x;
@@ -911,19 +911,24 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int n = tid + i * 256;
-        if (n < N) y[(size_t)m * N + n] = (v[i] - mean) * rstd * gam[i] + bet[i];
+        if (n < N) {
+            // chunk_rows > 0: chunk-major output for fnet_dense_kernel, [sample = m / chunk_rows][n / 4][32 rows][4] (fnet_dense.hip)
+            const size_t o = chunk_rows > 0 ? (size_t)(m / chunk_rows) * 32 * N + ((size_t)(n / 4) * 32 + m % chunk_rows) * 4 + n % 4
+                                            : (size_t)m * N + n;
+            y[o] = (v[i] - mean) * rstd * gam[i] + bet[i];
+        }
     }
 }
 
 hipError_t layernorm_launch(int x_dtype, const void* x, const float* add, int add_rows, const float* gamma,
-                            const float* beta, float eps, float* y, int M, int N, hipStream_t s) {
-    if (N > 2048) return hipErrorInvalidValue;
+                            const float* beta, float eps, float* y, int M, int N, hipStream_t s, int chunk_rows) {
+    if (N > 2048 || chunk_rows > 32 || (chunk_rows > 0 && (N % 4 || M % chunk_rows))) return hipErrorInvalidValue;
     if (x_dtype == DT_BF16)
         hipLaunchKernelGGL(layernorm_kernel<__bf16>, dim3(M), dim3(256), 0, s, (const __bf16*)x, add, add_rows, gamma, beta,
-                           eps, y, N);
+                           eps, y, N, chunk_rows);
     else
         hipLaunchKernelGGL(layernorm_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)x, add, add_rows, gamma, beta,
-                           eps, y, N);
+                           eps, y, N, chunk_rows);
     return hipGetLastError();
 }
 
