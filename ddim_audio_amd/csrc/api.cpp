@@ -1148,6 +1148,19 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     if ((long long)w.total > workspace_bytes) return fail("workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
     hipStream_t s = (hipStream_t)stream, sa = (hipStream_t)aux_stream;
     if (!sa || !events || n_events < 2 || B < 2) fork_mask = 0;
+    // bits 20-23: STAGGER level.  The two shards otherwise run in lock step -- both in the bandwidth-bound shallow levels or both in
+    // the latency-bound middle of the network at the same time.  With a stagger level l (only with every level and the FNet sharded)
+    // shard 1 starts when shard 0 has finished the down path of level l - 1: one shard's deep levels and FNet then run under the
+    // other's level 0-2 convolutions.  Same launches per shard, same results bit for bit; the host enqueues shard 0's whole walk, an
+    // event at the stagger point, then shard 1's walk behind that event (a captured graph gets the edge).
+    int stagger = (int)((fork_mask >> 20) & 0xFu);
+    fork_mask &= 0xFFFFFu;
+    {
+        unsigned all = 1u << 16;
+        for (int l = 0; l < L; ++l) all |= 1u << l;
+        if ((fork_mask & all) != all || stagger >= L || n_events < 3) stagger = 0;
+    }
+    int only = -1;  // lane filter of the staggered walk: 0 / 1 = only that shard's launches, -1 = both
     int ev_used = 0;  // every fork and every join records an event of its own: nothing is re-recorded inside one capture
     const int dt = c->dtype;
     const size_t es = esz(dt);
@@ -1175,8 +1188,9 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     auto for_lanes = [&](bool sharded, auto&& op) -> int {
         CHK(sync_for(sharded));
         if (!sharded) return op(Lane{0, B, s});
-        CHK(op(Lane{bh, B - bh, sa}));
-        return op(Lane{0, bh, s});
+        if (only != 0) CHK(op(Lane{bh, B - bh, sa}));
+        if (only != 1) CHK(op(Lane{0, bh, s}));
+        return 0;
     };
     auto at = [&](const void* p, size_t per_sample, int b0) { return (void*)((char*)const_cast<void*>(p) + per_sample * b0); };
     // scratch shared by all levels (h1 / h2, statistics, scale / shift): a shard's share starts at b0 x (the most one sample
@@ -1204,6 +1218,9 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
         });
     };
 
+    hipEvent_t stag_ev = nullptr;
+    auto walk = [&]() -> int {
+    cur = 0;
     // ---- down path (models/diffusion.py:252-264) ----
     const size_t in_per = (size_t)f.in_channels * T * f.f_size;  // fp32 NCHW elements per sample at the network boundary
     CHK(for_lanes(lvl_on(0), [&](const Lane& ln) -> int {
@@ -1216,6 +1233,11 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     int bi = 0;
     for (int l = 0; l < L; ++l) {
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        if (only == 0 && l == stagger && l > 0) {  // shard 0 is done with the down path of level l - 1: shard 1 may start
+            if (ev_used >= n_events) return fail("ddimx_unet_fwd_forked: no event left for the stagger point");
+            stag_ev = (hipEvent_t)events[ev_used++];
+            HIPCHK(hipEventRecord(stag_ev, s));
+        }
         if (l > 0) {
             CHK(for_lanes(lvl_on(l), [&](const Lane& ln) -> int {
                 ConvCall d = {dt, DOWN4, f.ch[l - 1], C, at(xcur, act_bytes(l - 1), ln.b0), pv(c, packed, c->down_w[l]),
@@ -1289,6 +1311,19 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
                                pf(c, packed, c->out_b), eps + in_per * ln.b0, ln.n, f.ch[0], f.in_channels, T, f.f_size, ln.st));
         return 0;
     }));
+    return 0;
+    };  // walk
+    if (stagger > 0) {
+        only = 0;
+        CHK(walk());
+        if (!stag_ev) return fail("ddimx_unet_fwd_forked: stagger point not reached");
+        HIPCHK(hipStreamWaitEvent(sa, stag_ev, 0));
+        only = 1;
+        CHK(walk());
+        only = -1;
+    } else {
+        CHK(walk());
+    }
     CHK(sync_for(false));  // leave with everything joined into `stream`
     return 0;
 }

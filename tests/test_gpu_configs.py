@@ -518,7 +518,7 @@ def test_forked_forward_is_bit_identical_for_every_mask(mode):
     with torch.no_grad():
         m.fork_mask = 0
         ref = m(x, t).clone()
-        for mask in (0x1, 0x3, 0x10000, 0x10003, 0x24, 0x1003F):
+        for mask in (0x1, 0x3, 0x10000, 0x10003, 0x24, 0x1003F, 0x31003F, 0x11003F):  # (bits 20-23: staggered shards)
             m.fork_mask = mask
             assert torch.equal(m(x, t), ref), hex(mask)
             assert torch.equal(m(x[:4], t[:4]), ref[:4]), hex(mask)
