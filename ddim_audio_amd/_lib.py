@@ -38,6 +38,7 @@ _SIGS = {
     "ddimx_packed_bytes": (c_longlong, [c_void_p]),
     "ddimx_workspace_bytes": (c_longlong, [c_void_p, c_int, c_int]),
     "ddimx_pack_weights": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "ddimx_pack_fnet_inference": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ddimx_unet_fwd": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_void_p]),
     "ddimx_unet_fwd_forked": (c_int, [c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_void_p,

@@ -160,6 +160,7 @@ struct ddimx_ctx {
     std::vector<FX> fx;
     size_t fx_proj = 0, fx_coutf = 0, fx_coutb = 0;
     bool fx_on = false;
+    const void* fx_packed = nullptr;  // the packed buffer whose fnet_dense copies are current (ddimx_pack_fnet_inference), else null
     std::vector<int> emb_off_down, emb_off_up;  // temb chunk offsets per block, execution order
     const unsigned long long* dropout_ctr = nullptr;  // device counter added to every dropout seed (ddimx_set_dropout_counter)
 };
@@ -936,7 +937,7 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
     const float eps = f.fnet_ln_eps;
     const int bf = c->fnet_bf16;
-    const bool dense = c->fx_on && knobs().fnet_dense != 0 && knobs().fnet_mix != 0 && fnet_mix_supported(S, hid) &&
+    const bool dense = c->fx_on && c->fx_packed == packed && knobs().fnet_dense != 0 && knobs().fnet_mix != 0 && fnet_mix_supported(S, hid) &&
                        fnet_dense_supported(S, hid, inter) && fnet_dense_supported(S, inter, hid) && fnet_dense_supported(S, width, hid) &&
                        fnet_dense_supported(S, hid, width);
     HIPCHK(layernorm_launch(c->dtype, x, tb->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps, w.ln0, M,
@@ -1057,6 +1058,7 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
     if (!h || !params || !packed) return fail("ddimx_pack_weights: null argument");
     if (n_params != (int)h->specs.size()) return fail("ddimx_pack_weights: got %d tensors, plan has %zu", n_params, h->specs.size());
     hipStream_t s = (hipStream_t)stream;
+    if (h->fx_packed == packed) h->fx_packed = nullptr;  // the folded FNet copies of this buffer are stale from here on
     const int C5 = h->cfg.ch[h->L - 1], Fr = h->Fr;
     PackCopyBatch batch;  // plain copies (norm weights, biases, dense matrices) go out in batches of kMax per launch
     batch.count = 0;
@@ -1097,7 +1099,18 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         }
     }
     HIPCHK(pack_copy_multi_launch(batch, s));
-    if (h->fx_on) {  // from the packed fp32 copies just written (stream order)
+    return 0;
+}
+
+// The inference-only second copies of the FNet weights (fnet_dense.hip: fragment order, LayerNorm gamma / beta folded in, per-layer
+// DFT tables), from the fp32 copies ddimx_pack_weights wrote into `packed` (stream order).  Separate because a training step
+// re-packs after every optimizer step and never reads them (38 launches); the host calls it when it packs for eval mode.
+// Without it the inference walk must not take the dense FNet path: `ready` is kept in the handle.
+int ddimx_pack_fnet_inference(ddimx_handle h, void* packed, void* stream) {
+    if (!h || !packed) return fail("ddimx_pack_fnet_inference: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    h->fx_packed = nullptr;
+    if (h->fx_on) {
         const ddimx_ctx* c = h;
         const ddimx_config& f = c->cfg;
         const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, bf = c->fnet_bf16;
@@ -1118,6 +1131,7 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         const ddimx_ctx::FL& LL = c->fl[f.fnet_layers - 1];
         HIPCHK(fnet_fold_launch(pf(c, packed, c->cout_w), pf(c, packed, LL.ln2_w), pf(c, packed, LL.ln2_b), pf(c, packed, c->cout_b),
                                 pk + c->fx_coutf, bf, (float*)(pk + c->fx_coutb), width, hid, s));
+        h->fx_packed = packed;
     }
     return 0;
 }

@@ -439,6 +439,9 @@ class Model(_Node):
         self._dirty = False
         self._temb_table = None
         if not self.training:
+            # eval mode only (a training step re-packs after every optimizer step and reads neither): the FNet's fragment-order /
+            # LayerNorm-folded copies for the launch-lean bottleneck path, and the BetaEmbedding table
+            _lib.check(lib.ddimx_pack_fnet_inference(self._handle, _lib.ptr(self._packed), _lib.stream()))
             self._build_temb_table(lib, device, tensors)
 
     def _build_temb_table(self, lib, device, tensors):
