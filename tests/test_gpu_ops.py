@@ -241,6 +241,43 @@ def test_fnet_dense_path_vs_oracle_and_batch_independence(act, fnet, mx, rms, s)
     assert torch.equal(run(tok[1:2])[0], y[1]), "a sample's FNet output depends on its batch neighbours"
 
 
+def test_fnet_dense_and_gemm_paths_agree_and_follow_the_packing():
+    """ddimx_pack_weights alone (what a training step's repack does) leaves the FNet's inference-only copies stale, and the forward
+    must then take the GEMM path; ddimx_pack_fnet_inference brings the launch-lean path back.  Both paths compute the same function
+    (models/diffusion.py:148-167): fp32 mode, S = 32 -- equal to rounding; the dense path before and after is bit-identical."""
+    import ctypes
+    lib = _lib.load()
+    m = _fnet_model("FloatTensor", "FloatTensor")
+    dev = G.dev()
+    s, t_len = 32, 1024
+    lib2 = m._ensure_handle()
+    with torch.cuda.device(dev):
+        m._ensure_packed(lib2, dev)
+        pe, dh, ds = m._ensure_tables(t_len, dev)
+    tok = synth.gaussian("fnet.paths.x", (2, s, 2048))
+    x = tok.view(2, s, 256, 8).permute(0, 1, 3, 2).contiguous().to(dev, m._act_dtype)
+    ws = torch.empty(int(lib.ddimx_workspace_bytes(m._handle, 2, t_len)), dtype=torch.uint8, device=dev)
+    tb = _lib.DdimxTables(pe.data_ptr(), dh.data_ptr(), ds.data_ptr())
+
+    def run():
+        out = torch.full((2 * s, 2048), float("nan"), device=dev)
+        _lib.check(lib.ddimx_fnet_fwd(m._handle, _lib.ptr(m._packed), ctypes.byref(tb), _lib.ptr(ws), ws.numel(), _lib.ptr(x), _lib.ptr(out),
+                                      2, t_len, _lib.stream()))
+        return out.cpu()
+
+    dense = run()
+    tensors = m._state_tensors()
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    _lib.check(lib.ddimx_pack_weights(m._handle, arr, len(tensors), _lib.ptr(m._packed), _lib.stream()))
+    gemm = run()
+    assert torch.isfinite(gemm).all()
+    assert not torch.equal(gemm, dense), "the repack should have sent the forward down the GEMM path"
+    sd = float(dense.double().std())
+    assert float((gemm - dense).abs().max()) / sd <= 2e-5
+    _lib.check(lib.ddimx_pack_fnet_inference(m._handle, _lib.ptr(m._packed), _lib.stream()))
+    assert torch.equal(run(), dense)
+
+
 # ---- edge convolutions as single ops -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("cin,c0,hw,b", [(2, 32, (40, 256), 2), (2, 32, (7, 24), 3), (2, 64, (9, 16), 2)])
