@@ -22,7 +22,7 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int fnet_dense, conv_ws;
+    int fnet_dense, conv_ws, wps_c64, wps_c96, wps_c128, du_min_tiles;
     int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold, conv_wreg;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -33,6 +33,8 @@ struct Knobs {
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
         fnet_dense = geti("DDIMX_FNET_DENSE", 1);
+        du_min_tiles = geti("DDIMX_DU_MIN_TILES", 2);  // Down / Upsample through conv3_wreg_kernel: at least two tiles per workgroup from 64 tiles per sample up (+0.5-1 %)
+        wps_c64 = geti("DDIMX_WPS_C64", 0); wps_c96 = geti("DDIMX_WPS_C96", 0); wps_c128 = geti("DDIMX_WPS_C128", 0);  // tuning hooks: workgroups per sample of the 3x3 convs of one width
         conv_ws = geti("DDIMX_CONV_WS", 0);  // opt-in: the wave-specialised kernel (conv_ws.h) -- correct and tested, but no faster
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
         two_tiles = geti("DDIMX_TWO_TILES", 0);
@@ -553,6 +555,16 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
         int wps = tiles_s < 128 ? tiles_s : 128;
         if (tiles_s / 4 > wps) wps = tiles_s / 4;
         if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
+        // level 2 (C = 96, twelve-wave workgroups): two tiles per workgroup -- the 6.7 us prologue (GroupNorm partials, weight
+        // warm-up, first halo) is paid once per 2 x 5 us of tile work instead of once per 5: +1.5-2 % sample-fwd/s at B = 8 with
+        // the two shards in flight (same-box A/B, DDIMX_WPS_C96 = 32 vs 64; four tiles: -4 %; the same at C = 64 / 128: -1 / -2.5 %)
+        if (q.mode == CONV3 && q.cin == 96 && tiles_s >= 4 && wps > tiles_s / 2) wps = tiles_s / 2;
+        if (q.mode == CONV3) {
+            const int v = q.cin == 64 ? knobs().wps_c64 : (q.cin == 96 ? knobs().wps_c96 : (q.cin == 128 ? knobs().wps_c128 : 0));
+            if (v > 0) wps = v < tiles_s ? v : tiles_s;
+        } else if (knobs().du_min_tiles > 1 && tiles_s >= 64 && cdiv(tiles_s, wps) < knobs().du_min_tiles) {
+            wps = tiles_s / knobs().du_min_tiles;
+        }
         p->tiles_per_wg = cdiv(tiles_s, wps);
         p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
         return 0;
