@@ -22,7 +22,7 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int fnet_dense, conv_ws, wps_c64, wps_c96, wps_c128, du_min_tiles;
+    int fnet_dense, conv_ws, wps_c32, wps_c64, wps_c96, wps_c128, du_min_tiles;
     int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold, conv_wreg;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -34,6 +34,7 @@ struct Knobs {
         fnet_mix = geti("DDIMX_FNET_MIX", 1);
         fnet_dense = geti("DDIMX_FNET_DENSE", 1);
         du_min_tiles = geti("DDIMX_DU_MIN_TILES", 2);  // Down / Upsample through conv3_wreg_kernel: at least two tiles per workgroup from 64 tiles per sample up (+0.5-1 %)
+        wps_c32 = geti("DDIMX_WPS_C32", 0);
         wps_c64 = geti("DDIMX_WPS_C64", 0); wps_c96 = geti("DDIMX_WPS_C96", 0); wps_c128 = geti("DDIMX_WPS_C128", 0);  // tuning hooks: workgroups per sample of the 3x3 convs of one width
         conv_ws = geti("DDIMX_CONV_WS", 0);  // opt-in: the wave-specialised kernel (conv_ws.h) -- correct and tested, but no faster
         splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
@@ -609,6 +610,7 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
     // run B = 4 launches, for which it halves an already half-empty grid: 1 803 vs 1 814 sample-fwd/s.
     if (knobs().two_tiles && g.nb == g.nout && g.lds_bytes > 80 * 1024 && tiles_s >= 64 && tiles_s <= 128 && q.mode == CONV3) wps = tiles_s / 2;
     if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
+    if (const int v = knobs().wps_c32; v > 0 && q.mode == CONV3 && q.cin == 32 && !q.batch_plan && !g_batch_plan) wps = v < tiles_s ? v : tiles_s;
     p->tiles_per_wg = cdiv(tiles_s, wps);
     p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
     return 0;
