@@ -41,7 +41,7 @@ struct WregArgs {
     int dbg;                     // diagnostic builds only
 };
 
-template <int CIN_, int COUT_, int MODE_, int TH_, int TW_, int WM_, int WN_, int D_, int NS_ = 1>
+template <int CIN_, int COUT_, int MODE_, int TH_, int TW_, int WM_, int WN_, int D_, int NS_ = 1, int KS_ = 1>
 struct WregCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, MODE = MODE_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, D = D_;
     // CONV3: 3x3 stride 1 (Residual_Block); DOWN4: 4x4 stride 2 (Downsample); UP4: ConvTranspose2d 4x4 stride 2 (Upsample) as
@@ -54,10 +54,14 @@ struct WregCfg {
                                         // have too few pixels to fill 256 CUs otherwise; each stages the small halo for itself)
     static constexpr int NB = COUT / NS;   // output channels of one workgroup
     static constexpr int ES = 2, EPB = 8;
-    static constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
+    static constexpr int KS = KS_;      // K splits: KS wave groups share a (pixel block, cout block) and take NSTEP / KS steps each; the deep
+                                        // levels are a dependent chain of 72-144 steps per wave on an otherwise empty chip (0.5-1.1
+                                        // resident waves per SIMD, profiles/r03/final/step_pmc.txt); the partial accumulators meet in LDS
+    static constexpr int NWAVES = WM * WN * KS, NTHREADS = 64 * NWAVES;
     static constexpr int P = TH * TW;
     static constexpr int MT = P / (32 * WM), NT = NB / (32 * WN);
-    static constexpr int KG = CIN / 16, NSTEP = NTAPS * KG, NBLK = COUT / 32;
+    static constexpr int KACC_BYTES = (KS - 1) * WM * WN * MT * 16 * 64 * 4;  // partial accumulators of the wave groups ks > 0
+    static constexpr int KG = CIN / 16, NSTEP = NTAPS * KG, NBLK = COUT / 32, NSL = NSTEP / KS;
     static constexpr int IH = SXY * TH + 2, IW = SXY * TW + 2, NPIX = IH * IW;
     static constexpr int PSTRIDE = CIN * ES + 16;
     static constexpr int ROWRAW = IW * PSTRIDE;
@@ -70,7 +74,7 @@ struct WregCfg {
     static constexpr int ADD_BYTES = NB * 4;
     static constexpr int GN_BYTES = NWAVES * kGroups * 2 * 4;
     static constexpr int RED_BYTES = NWAVES * NB * 2 * 4;
-    static constexpr int LDS_RAW = ADD_BYTES + HO_BYTES + GN_BYTES + 256;  // + 256 B sink of the weight warm-up touches
+    static constexpr int LDS_RAW = ADD_BYTES + HO_BYTES + KACC_BYTES + GN_BYTES + 256;  // + 256 B sink of the weight warm-up touches
     static constexpr int LDS_BYTES = LDS_RAW > RED_BYTES ? LDS_RAW : RED_BYTES;
     static constexpr int CPP = CIN / EPB, LPP = next_pow2(CPP);
     static constexpr int PPP = NTHREADS / LPP, HPT = (NPIX + PPP - 1) / PPP;
@@ -85,7 +89,7 @@ struct WregCfg {
     static_assert(P % (32 * WM) == 0 && MT >= 1, "pixel tile must split into 32-pixel MFMA blocks");
     static_assert(TW == 8 || TW == 16 || TW == 32, "TW");
     static_assert((PSTRIDE / 16) % 2 == 1, "pixel stride must be odd in 16-byte slots");
-    static_assert(D >= 2 && D <= NSTEP && NSTEP % D == 0, "prefetch depth (the register ring wraps into the next tile: D must divide the step count)");
+    static_assert(NSTEP % KS == 0 && D >= 2 && D <= NSL && NSL % D == 0, "prefetch depth (the register ring wraps into the next tile: D must divide the step count of a wave)");
     static_assert(NTHREADS % LPP == 0 && NTHREADS % OLPP == 0 && OLPP <= 64 && NTHREADS <= 1024, "thread maps");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(HPT <= 24, "halo pieces per thread (all of a tile's loads are kept in registers)");
@@ -101,11 +105,12 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     char* const halo = smem + F::ADD_BYTES;
     char* const otile = halo;
     float* const gnscr = (float*)(smem + F::LDS_RAW - F::GN_BYTES - 256);
+    float* const kacc = (float*)(smem + F::ADD_BYTES + F::HO_BYTES);
     char* const sink = smem + F::LDS_RAW - 256;
 
     DDIMX_STAMP_ENTRY
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % F::WM, wn = wave / F::WM;
+    const int wm = wave % F::WM, wn = (wave / F::WM) % F::WN, ks = wave / (F::WM * F::WN);
     const int l31 = lane & 31, h = lane >> 5;
 
     int lwg;  // XCD-aware order (as conv_mfma_kernel)
@@ -166,7 +171,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
     }
     uint4 aw[F::D];
 #pragma unroll
-    for (int d = 0; d < F::D; ++d) aw[d] = wfrag(d);
+    for (int d = 0; d < F::D; ++d) aw[d] = wfrag(ks * F::NSL + d);
 
     // ---- halo staging (register transform, as conv_mfma_kernel's general path) ----------------------------------------------
     const int hc = tid % F::LPP, hslot = tid / F::LPP;
@@ -309,26 +314,64 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
         // ---- MFMA loop: step s = (tap, 16-channel group).  A = aw[s % D] (loaded D steps ago, possibly during the previous tile),
         // B = bq[s & 1] (LDS, loaded one step ago); the scheduling barriers keep hipcc from sinking the loads down to their use.
         uint4 bq[2][F::MT];
+        auto run_steps = [&](auto ks_tag) __attribute__((always_inline)) {  // this wave's NSL steps (offsets are compile-time per KS group)
+            constexpr int S0 = decltype(ks_tag)::value * F::NSL;
+            {
+                constexpr int tap = S0 / F::KG, kg = S0 % F::KG;
+                constexpr int hoff = (tap / F::TAPW) * F::ROWSTRIDE + (tap % F::TAPW) * F::PSTRIDE + kg * 32;
 #pragma unroll
-        for (int m = 0; m < F::MT; ++m) bq[0][m] = *(const uint4*)(halo + pixoff[m]);
-#pragma unroll
-        for (int s = 0; s < F::NSTEP; ++s) {
-            if (s + 1 < F::NSTEP) {
-                const int tap = (s + 1) / F::KG, kg = (s + 1) % F::KG;
-                const int hoff = (tap / F::TAPW) * F::ROWSTRIDE + (tap % F::TAPW) * F::PSTRIDE + kg * 32;
-#pragma unroll
-                for (int m = 0; m < F::MT; ++m) bq[(s + 1) & 1][m] = *(const uint4*)(halo + pixoff[m] + hoff);
+                for (int m = 0; m < F::MT; ++m) bq[0][m] = *(const uint4*)(halo + pixoff[m] + hoff);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const uint4 af = aw[s % F::D];
 #pragma unroll
-            for (int m = 0; m < F::MT; ++m) Mma<T>::run(af, bq[s & 1][m], acc[m]);
-            aw[s % F::D] = wfrag((s + F::D) % F::NSTEP);  // wraps into the next tile: the weights do not depend on the tile
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < F::NSL; ++s) {
+                if (s + 1 < F::NSL) {
+                    const int tap = (S0 + s + 1) / F::KG, kg = (S0 + s + 1) % F::KG;
+                    const int hoff = (tap / F::TAPW) * F::ROWSTRIDE + (tap % F::TAPW) * F::PSTRIDE + kg * 32;
+#pragma unroll
+                    for (int m = 0; m < F::MT; ++m) bq[(s + 1) & 1][m] = *(const uint4*)(halo + pixoff[m] + hoff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const uint4 af = aw[s % F::D];
+#pragma unroll
+                for (int m = 0; m < F::MT; ++m) Mma<T>::run(af, bq[s & 1][m], acc[m]);
+                aw[s % F::D] = wfrag(S0 + (s + F::D) % F::NSL);  // wraps into the next tile: the weights do not depend on the tile
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (F::KS == 1) {
+            run_steps(std::integral_constant<int, 0>());
+        } else {
+            static_assert(F::KS == 2, "K split");
+            if (ks == 0) run_steps(std::integral_constant<int, 0>()); else run_steps(std::integral_constant<int, 1>());
         }
         DDIMX_STAMP_AT(1);
-        __syncthreads();  // barrier A: every wave is done reading this tile's halo
+        if constexpr (F::KS > 1) {  // the partial accumulators of the wave groups ks > 0 go through LDS (a region of their own)
+            if (ks > 0) {
+                float* dstp = kacc + (((ks - 1) * F::WN + wn) * F::WM + wm) * (F::MT * 16 * 64) + lane * 4;
+#pragma unroll
+                for (int m = 0; m < F::MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(dstp + (m * 4 + q) * 256) = make_float4(acc[m][q * 4 + 0], acc[m][q * 4 + 1], acc[m][q * 4 + 2], acc[m][q * 4 + 3]);
+            }
+        }
+        __syncthreads();  // barrier A: every wave is done reading this tile's halo (and the partial accumulators are in LDS)
         DDIMX_STAMP_AT(2);
+        if constexpr (F::KS > 1) {
+            if (ks == 0) {
+#pragma unroll
+                for (int k2 = 1; k2 < F::KS; ++k2) {
+                    const float* srcp = kacc + (((k2 - 1) * F::WN + wn) * F::WM + wm) * (F::MT * 16 * 64) + lane * 4;
+#pragma unroll
+                    for (int m = 0; m < F::MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 pv = *(const float4*)(srcp + (m * 4 + q) * 256);
+                            acc[m][q * 4 + 0] += pv.x; acc[m][q * 4 + 1] += pv.y; acc[m][q * 4 + 2] += pv.z; acc[m][q * 4 + 3] += pv.w;
+                        }
+                }
+            }
+        }
 
         // ---- epilogue 1: accumulators + addend -> SiLU -> bf16 -> output tile [pixel][cout] (overlays the halo) ------------------
         auto epi1 = [&](auto act_tag) __attribute__((always_inline)) {
@@ -351,7 +394,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_wreg_kernel(const 
                 }
             }
         };
-        if (a.act) epi1(std::integral_constant<int, 1>()); else epi1(std::integral_constant<int, 0>());
+        if (F::KS == 1 || ks == 0) { if (a.act) epi1(std::integral_constant<int, 1>()); else epi1(std::integral_constant<int, 0>()); }
         DDIMX_STAMP_AT(3);
         __syncthreads();  // barrier B: output tile complete
         DDIMX_STAMP_AT(5);
