@@ -435,7 +435,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: batch {B}/GPU x [2,{T},256] spectrograms, audio.yml U-Net (47.2M params, "
                                    f"hash-filled weights; FNet GEMM operands {args.fnet_dtype or args.dtype}), generalized_steps eta=0 over the 1000-step "
-                                   f"schedule, one hipGraph per step ({len(stepper.bounds)} stepper branch(es); inside the forward two batch shards on two "
+                                   f"schedule, one hipGraph per step (inside the forward two batch shards on two "
                                    f"streams, fork mask {model.fork_mask:#x})",
                        "global_batch": world * B, "t_size": T, "parallelism": f"batch-sharded x{world}, no collective in the loop"},
             "iters_per_s": iters_per_s,

@@ -72,8 +72,6 @@ _SIGS = {
     "ddimx_resblock_bwd": (c_int, [c_int, c_int] + [c_void_p] * 20 + [c_int, c_void_p] + [c_int] * 3 + [c_void_p]),
     "ddimx_conv3x3_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ddimx_conv3x3_fold_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                       c_int, c_int, c_int, c_void_p]),
     "ddimx_debug_set_stamps": (c_int, [c_void_p]),
     "ddimx_pack_conv_frag": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ddimx_pack_conv_frag_k": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -81,9 +79,9 @@ _SIGS = {
     "ddimx_pack_frag_from_taps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddimx_upsample_add_wreg_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                             c_void_p]),
-    "ddimx_conv3x3_ws_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
-                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ddimx_conv3x3_ws_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "ddimx_conv3x3_pipe_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddimx_conv3x3_pipe_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "ddimx_conv3x3_wreg_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddimx_conv3x3_stats_floats": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),

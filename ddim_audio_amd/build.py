@@ -13,8 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libddimx.so")
 SOURCES = ["api.cpp", "kernels.hip", "gemm.hip", "fnet_dense.hip", "conv_inst_bf16_c3.hip", "conv_inst_bf16_du.hip",
-           "conv_inst_f32_c3.hip", "conv_inst_f32_du.hip", "conv_inst_bf16_c3b.hip", "conv_inst_bf16_fold.hip", "conv_inst_bf16_wreg.hip", "conv_inst_bf16_ws.hip", "conv_inst_f32_c3b.hip", "train_kernels.hip", "wgrad_inst_bf16.hip", "wgrad_inst_f32.hip"]
+           "conv_inst_f32_c3.hip", "conv_inst_f32_du.hip", "conv_inst_bf16_c3b.hip", "conv_inst_bf16_wreg.hip", "conv_inst_bf16_pipe.hip", "conv_inst_f32_c3b.hip", "train_kernels.hip", "wgrad_inst_bf16.hip", "wgrad_inst_f32.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
+# conv_pipe.h: MFMA accumulators in VGPRs (the epilogue reads them with plain vector instructions, no v_accvgpr_read per element)
+# and no SLP packing of its scalar f32 arithmetic into v_pk_*_f32 (an anti-lever beside MFMAs, MI355X_MICROARCH.md)
+EXTRA_FLAGS = {"conv_inst_bf16_pipe.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale(target, deps):
@@ -45,7 +48,7 @@ def build(force=False, verbose=True, jobs=None, stamp=False):
 
     def cc(job):
         sp, ob = job
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", ob]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", ob]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (sp, r.stderr[-4000:]))

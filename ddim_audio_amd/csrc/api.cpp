@@ -15,37 +15,24 @@
 #include "kernels.h"
 #include "train_kernels.h"
 #include "wgrad_mfma.h"
-#include "conv_fold.h"
-#include "conv_ws.h"
+#include "conv_pipe.h"
 
 namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int fnet_dense, conv_ws, wps_c32, wps_c64, wps_c96, wps_c128, du_min_tiles;
-    int conv_var, conv_wps, wgrad_split, fnet_mix, splitk_cap, two_tiles, gn_dbg, bwd_stats_fused, conv_stagger, conv_fold, conv_wreg;
+    int fnet_dense, conv_pipe, pipe_tpw, bwd_stats_fused, gn_dbg, conv_wreg, conv_wps, conv_var, wgrad_split;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-        conv_var = geti("DDIMX_CONV_VAR", -1);
-        conv_wps = geti("DDIMX_CONV_WPS", 0);
-        bwd_stats_fused = geti("DDIMX_BWD_STATS_FUSED", 1);  // A/B hook: 0 = GroupNorm-backward statistics by their own pass
-        gn_dbg = geti("DDIMX_GN_DBG", 0);  // A/B hook: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
-        wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);
-        fnet_mix = geti("DDIMX_FNET_MIX", 1);
-        fnet_dense = geti("DDIMX_FNET_DENSE", 1);
-        du_min_tiles = geti("DDIMX_DU_MIN_TILES", 2);  // Down / Upsample through conv3_wreg_kernel: at least two tiles per workgroup from 64 tiles per sample up (+0.5-1 %)
-        wps_c32 = geti("DDIMX_WPS_C32", 0);
-        wps_c64 = geti("DDIMX_WPS_C64", 0); wps_c96 = geti("DDIMX_WPS_C96", 0); wps_c128 = geti("DDIMX_WPS_C128", 0);  // tuning hooks: workgroups per sample of the 3x3 convs of one width
-        conv_ws = geti("DDIMX_CONV_WS", 0);  // opt-in: the wave-specialised kernel (conv_ws.h) -- correct and tested, but no faster
-        splitk_cap = geti("DDIMX_SPLITK_CAP", 0);
-        two_tiles = geti("DDIMX_TWO_TILES", 0);
-        conv_stagger = geti("DDIMX_CONV_STAGGER", 0);
-        // the folded-affine kernel (conv_fold.h) for the block's second conv at C = 32: OFF in the walk.  Alone it is faster than the
-        // register-transform kernel (74 vs 80 us per launch in the unforked step), but with two batch shards in flight the step is
-        // 0.9 % slower (2 208 vs 2 228 sample-fwd/s, same box: DESIGN section 9).  1 = on (A/B); the kernel stays reachable and
-        // tested through ddimx_conv3x3_fold_fwd.
-        conv_fold = geti("DDIMX_CONV_FOLD", 0);
-        conv_wreg = geti("DDIMX_CONV_WREG", 1);  // A/B hook: 0 = the 3x3 convs of C >= 64 keep the LDS weight ring (conv_mfma_kernel)  // A/B hook: 0 = the affine-input 3x3 convs keep the register-transform kernel
+        conv_var = geti("DDIMX_CONV_VAR", -1);     // tools/conv_tune.py: force a candidate tile variant of conv_mfma_kernel
+        conv_wps = geti("DDIMX_CONV_WPS", 0);      // tools/conv_tune.py: workgroups per sample
+        wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);  // tools/wgrad_one.py
+        bwd_stats_fused = geti("DDIMX_BWD_STATS_FUSED", 1);  // A/B: 0 = GroupNorm-backward statistics by their own pass
+        gn_dbg = geti("DDIMX_GN_DBG", 0);          // tools/gn_dbg.sh: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
+        fnet_dense = geti("DDIMX_FNET_DENSE", 1);  // tools/fnet_ab.sh: 0 = the GEMM path for the FNet at S <= 32
+        conv_wreg = geti("DDIMX_CONV_WREG", 1);    // tools/step_ab.sh: 0 = the convs of C >= 64 keep the LDS weight ring (conv_mfma_kernel)
+        conv_pipe = geti("DDIMX_CONV_PIPE", 1);    // tools/step_ab.sh: 0 = levels 0-1 keep conv_mfma_kernel / conv3_wreg_kernel
+        pipe_tpw = geti("DDIMX_PIPE_TPW", 0);      // tools/pipe_time.py: tiles per workgroup of conv3_pipe_kernel
     }
 };
 static const Knobs& knobs() {
@@ -198,8 +185,8 @@ static RBW add_rb(ddimx_ctx* c, const std::string& p, int C, int k) {
     r.w1 = add_spec(c, p + "conv.1.weight", PK_CONV, C, C, k, k);
     r.bias1 = add_spec(c, p + "conv.1.bias", PK_COPY, C);
     WregGeom wg;
-    WsGeom wsg;
-    if (c->dtype == DT_BF16 && k == 3 && (wreg_geometry(CONV3, C, C, &wg) == hipSuccess || ws_geometry(C, &wsg) == hipSuccess)) {  // second copy in MFMA fragment order
+    PipeGeom pg;
+    if (c->dtype == DT_BF16 && k == 3 && (wreg_geometry(CONV3, C, C, &wg) == hipSuccess || pipe_geometry(C, &pg) == hipSuccess)) {  // second copy in MFMA fragment order
         c->frag_off.resize(c->specs.size(), 0);
         for (int i : {r.w0, r.w1}) {
             c->frag_off[i] = c->packed_bytes;
@@ -339,7 +326,6 @@ static int build_plan(ddimx_ctx* c) {
 constexpr int kMaxSplitK = 8;
 static inline int sample_splitk(int rows_per_sample, int N, int K, int bf16) {
     int s = gemm_pick_splitk(rows_per_sample, N, K, 1, bf16);
-    if (const int cap = knobs().splitk_cap; cap > 0 && s > cap) s = cap;  // tuning hook (a constant cap keeps the batch invariance)
     return s;
 }
 
@@ -377,14 +363,14 @@ static size_t conv_stats_floats(int dtype, int mode, int cin, int cout, int B, i
         if (n > mx) mx = n;
     }
     if (mode == CONV3 && cin == cout && dtype == DT_BF16) {  // the specialised kernels partition a sample into their own tiles
-        FoldGeom fg;
         WregGeom wg;
-        if (fold_geometry(cin, &fg) == hipSuccess) {
-            const size_t n = (size_t)B * cdiv(Wv, fg.tw) * cdiv(Hv, fg.th) * cout * 2;
-            if (n > mx) mx = n;
-        }
         if (wreg_geometry(CONV3, cin, cout, &wg) == hipSuccess) {
             const size_t n = (size_t)B * cdiv(Wv, wg.tw) * cdiv(Hv, wg.th) * cout * 2;
+            if (n > mx) mx = n;
+        }
+        PipeGeom pg;  // (one 32-float slab per workgroup of >= 1 tile)
+        if (pipe_geometry(cin, &pg) == hipSuccess) {
+            const size_t n = (size_t)B * cdiv(Wv, pg.tw) * cdiv(Hv, pg.th) * kGnSlab;
             if (n > mx) mx = n;
         }
     }
@@ -484,8 +470,7 @@ struct ConvCall {
     GnIn gn = {};             // gn.stats set: the input's GroupNorm is finished inside the kernel (in_scale / in_shift unused)
     bool groups = false;      // statistics partials in group format (gn_fused.h)
     const void* wf = nullptr; // the same weights in MFMA fragment order (conv_wreg.h), if the caller has them
-    int kernel_pref = 0;      // 0: the walk's choice; 1: never the wave-specialised kernel (conv_ws.h); 2: only it (per-op exports)
-    bool force_fold = false;  // ddimx_conv3x3_fold_fwd: take the folded-affine kernel whatever the DDIMX_CONV_FOLD default
+    int kernel_pref = 0;      // 0: the walk's choice; 1: never the software-pipelined kernel (conv_pipe.h); 2: only it (per-op exports)
 };
 
 // set for the duration of the whole-network training calls (see ConvCall::batch_plan)
@@ -495,16 +480,18 @@ struct BatchPlanScope {
     ~BatchPlanScope() { g_batch_plan = false; }
 };
 // Plan of one conv launch: tile configuration and the persistent-workgroup split.
-struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; bool fold, wreg, ws; };
-// The folded-affine kernel (conv_fold.h) takes a 3x3 conv whose input transform is a plain per-channel affine (the block's second
-// conv in the inference walk) when a configuration exists for the width and the image is a whole number of its tiles.  The
-// choice depends on the sample's size only (never on the batch).
-static bool fold_eligible(const ConvCall& q, FoldGeom* fg) {
-    if (!(knobs().conv_fold || q.force_fold) || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.xf != XF_AFFINE || q.act > 1 || q.skip ||
-        q.aux || q.bwd_mode || q.batch_plan || g_batch_plan)
+struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, wgs_per_sample; bool wreg, pipe; };
+// The software-pipelined kernel (conv_pipe.h) takes the Residual_Block convs of the inference walk at the widths it is instantiated
+// for (C = 32, 64): bf16, GroupNorm-affine (+ SiLU) input, SiLU output, group-format statistics, fragment-order weights, whole
+// tiles.  The choice depends on the sample's size only (never on the batch).
+static bool pipe_eligible(const ConvCall& q, PipeGeom* pg) {
+    if (q.kernel_pref == 1 || !(knobs().conv_pipe || q.kernel_pref == 2)) return false;
+    if (!q.wf || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.act != 1 || q.aux || q.bwd_mode || q.skip || q.batch_plan || g_batch_plan)
         return false;
-    if (fold_geometry(q.cin, fg) != hipSuccess) return false;
-    return q.Hin % fg->th == 0 && q.Win % fg->tw == 0;
+    if (q.xf != XF_AFFINE && q.xf != XF_AFFINE_SILU) return false;
+    if (q.stats && !q.groups) return false;
+    if (pipe_geometry(q.cin, pg) != hipSuccess) return false;
+    return q.Hin % pg->th == 0 && q.Win % pg->tw == 0;
 }
 // The register-streamed-weights kernel (conv_wreg.h) takes the 3x3 convs of the inference walk from C = 64 up when the caller has
 // the fragment-order weights and the image is a whole number of its tiles (sample size only, never the batch).
@@ -516,33 +503,28 @@ static bool wreg_eligible(const ConvCall& q, WregGeom* wg) {
     const int sxy = q.mode == DOWN4 ? 2 : 1;
     return q.Hin % (wg->th * sxy) == 0 && q.Win % (wg->tw * sxy) == 0;
 }
-// The wave-specialised kernel (conv_ws.h) takes the Residual_Block convs of the inference walk at the widths it is instantiated
-// for, under the same conditions (fragment-order weights, whole tiles; sample size only, never the batch).
-static bool ws_eligible(const ConvCall& q, WsGeom* wg) {
-    if (q.kernel_pref == 1 || !(knobs().conv_ws || q.kernel_pref == 2)) return false;
-    if (!q.wf || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.act > 1 || q.aux || q.bwd_mode || q.skip || q.batch_plan || g_batch_plan)
-        return false;
-    if (q.xf != XF_NONE && q.xf != XF_AFFINE && q.xf != XF_AFFINE_SILU) return false;
-    if (ws_geometry(q.cin, wg) != hipSuccess) return false;
-    return q.Hin % wg->th == 0 && q.Win % wg->tw == 0;
-}
 static int conv_plan(const ConvCall& q, ConvPlan* p) {
     ConvGeom& g = p->g;
-    p->fold = false;
     p->wreg = false;
-    p->ws = false;
-    WsGeom wsg;
-    if (ws_eligible(q, &wsg)) {
-        p->ws = true;
+    p->pipe = false;
+    PipeGeom pgm;
+    if (pipe_eligible(q, &pgm)) {
+        p->pipe = true;
         p->Hv = q.Hin; p->Wv = q.Win; p->var = 0;
-        g.th = wsg.th; g.tw = wsg.tw; g.nb = g.nout = q.cout; g.classes = 1; g.lds_bytes = wsg.lds_bytes; g.nthreads = wsg.nthreads;
-        p->tiles_x = q.Win / wsg.tw;
-        p->tiles_y = q.Hin / wsg.th;
-        p->tiles_per_wg = wsg.tiles_per_wg;
-        p->wgs_per_sample = cdiv(p->tiles_x * p->tiles_y, p->tiles_per_wg);
+        g.th = pgm.th; g.tw = pgm.tw; g.nb = g.nout = q.cout; g.classes = 1; g.lds_bytes = pgm.lds_bytes; g.nthreads = pgm.nthreads;
+        p->tiles_x = q.Win / pgm.tw;
+        p->tiles_y = q.Hin / pgm.th;
+        const int tiles_s = p->tiles_x * p->tiles_y;
+        // one workgroup per CU, persistent: 32 workgroups per T = 1024 sample (16 tiles at C = 32, 8 at C = 64), so that a batch of 8
+        // -- or its two shards of 4 on two streams -- is one round of 256 workgroups; long samples keep the tile count per workgroup
+        int tpw = q.cin == 32 ? 16 : 8;
+        if (const int v = knobs().pipe_tpw; v > 0) tpw = v;
+        if (tpw > tiles_s) tpw = tiles_s;
+        p->tiles_per_wg = tpw;
+        p->wgs_per_sample = cdiv(tiles_s, tpw);
         return 0;
     }
-    if (q.kernel_pref == 2) return fail("conv %d->%d %dx%d: not eligible for the wave-specialised kernel", q.cin, q.cout, q.Hin, q.Win);
+    if (q.kernel_pref == 2) return fail("conv %d->%d %dx%d xf=%d act=%d: not eligible for the software-pipelined kernel", q.cin, q.cout, q.Hin, q.Win, q.xf, q.act);
     WregGeom wgm;
     if (wreg_eligible(q, &wgm)) {
         p->wreg = true;
@@ -558,29 +540,10 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
         if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
         // level 2 (C = 96, twelve-wave workgroups): two tiles per workgroup -- the 6.7 us prologue (GroupNorm partials, weight
         // warm-up, first halo) is paid once per 2 x 5 us of tile work instead of once per 5: +1.5-2 % sample-fwd/s at B = 8 with
-        // the two shards in flight (same-box A/B, DDIMX_WPS_C96 = 32 vs 64; four tiles: -4 %; the same at C = 64 / 128: -1 / -2.5 %)
+        // the two shards in flight (same-box A/B, round 3; four tiles: -4 %; the same at C = 64 / 128: -1 / -2.5 %)
         if (q.mode == CONV3 && q.cin == 96 && tiles_s >= 4 && wps > tiles_s / 2) wps = tiles_s / 2;
-        if (q.mode == CONV3) {
-            const int v = q.cin == 64 ? knobs().wps_c64 : (q.cin == 96 ? knobs().wps_c96 : (q.cin == 128 ? knobs().wps_c128 : 0));
-            if (v > 0) wps = v < tiles_s ? v : tiles_s;
-        } else if (knobs().du_min_tiles > 1 && tiles_s >= 64 && cdiv(tiles_s, wps) < knobs().du_min_tiles) {
-            wps = tiles_s / knobs().du_min_tiles;
-        }
-        p->tiles_per_wg = cdiv(tiles_s, wps);
-        p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
-        return 0;
-    }
-    FoldGeom fg;
-    if (fold_eligible(q, &fg)) {
-        p->fold = true;
-        p->Hv = q.Hin; p->Wv = q.Win; p->var = 0;
-        g.th = fg.th; g.tw = fg.tw; g.nb = g.nout = q.cout; g.classes = 1; g.lds_bytes = fg.lds_bytes; g.nthreads = fg.nthreads;
-        p->tiles_x = q.Win / fg.tw;
-        p->tiles_y = q.Hin / fg.th;
-        const int tiles_s = p->tiles_x * p->tiles_y;
-        int wps = tiles_s < 128 ? tiles_s : 128;
-        if (tiles_s / 8 > wps) wps = tiles_s / 8;  // at most 8 tiles (one tile row at F = 256) per workgroup
-        if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
+        // Down / Upsample: at least two tiles per workgroup from 64 tiles per sample up (+0.5-1 %, round 3)
+        if (q.mode != CONV3 && tiles_s >= 64 && cdiv(tiles_s, wps) < 2) wps = tiles_s / 2;
         p->tiles_per_wg = cdiv(tiles_s, wps);
         p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
         return 0;
@@ -605,12 +568,7 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
     // per-workgroup costs (82 KB of weights, statistics tail): 114 -> 106 / 97 -> 88 / 61 -> 58 us at B = 8
     // (profiles/r02/downup_wps.txt); a single short sample pays about 12 us per launch for the emptier grid.
     if (q.mode != CONV3 && tiles_s == 128) wps = 64;
-    // A/B hook (off): two tiles per workgroup at level 2 (one workgroup per CU, 64-128 tiles per sample).  Alone the launch
-    // gains 9 % at B = 8 (44.1 -> 40.3 us, profiles/r02/conv_wps_deep_levels.txt), but inside the step the two batch shards
-    // run B = 4 launches, for which it halves an already half-empty grid: 1 803 vs 1 814 sample-fwd/s.
-    if (knobs().two_tiles && g.nb == g.nout && g.lds_bytes > 80 * 1024 && tiles_s >= 64 && tiles_s <= 128 && q.mode == CONV3) wps = tiles_s / 2;
     if (const int v = knobs().conv_wps; v > 0) wps = v < tiles_s ? v : tiles_s;
-    if (const int v = knobs().wps_c32; v > 0 && q.mode == CONV3 && q.cin == 32 && !q.batch_plan && !g_batch_plan) wps = v < tiles_s ? v : tiles_s;
     p->tiles_per_wg = cdiv(tiles_s, wps);
     p->wgs_per_sample = cdiv(tiles_s, p->tiles_per_wg);
     return 0;
@@ -632,36 +590,20 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     ConvPlan pl;
     CHK(conv_plan(q, &pl));
     const ConvGeom& g = pl.g;
-    if (pl.wreg || pl.ws) {
+    if (pl.wreg || pl.pipe) {
         WregArgs f;
         memset(&f, 0, sizeof(f));
         f.in = q.in; f.wf = q.wf; f.skip = q.skip; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
         f.in_scale = q.in_scale; f.in_shift = q.in_shift; f.gn = q.gn; f.out = q.out; f.stats = q.stats;
         f.stats_groups_c = q.groups ? q.cout : 0; f.xf = q.xf; f.act = q.act; f.stamps = q.stamps;
-        { static const int dbg = getenv("DDIMX_WS_DBG") ? atoi(getenv("DDIMX_WS_DBG")) : 0; f.dbg = dbg; }
         if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
         if (q.xf != XF_NONE && !q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
         f.B = q.B; f.H = q.Hin; f.W = q.Win;
         f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
         if (nparts) *nparts = f.wgs_per_sample * g.classes * (q.groups ? g.nout / g.nb : 1);
         if (Cs) *Cs = g.nout;
-        if (pl.ws) HIPCHK(ws_launch(q.cin, f, s));
+        if (pl.pipe) HIPCHK(pipe_launch(q.cin, q.xf, f, s));
         else HIPCHK(wreg_launch(q.mode, q.cin, g.nout, f, s));
-        return 0;
-    }
-    if (pl.fold) {
-        FoldArgs f;
-        memset(&f, 0, sizeof(f));
-        f.in = q.in; f.w = q.w; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
-        f.in_scale = q.in_scale; f.in_shift = q.in_shift; f.gn = q.gn; f.out = q.out; f.stats = q.stats;
-        f.stats_groups_c = q.groups ? q.cout : 0; f.act = q.act; f.stamps = q.stamps; f.stagger = knobs().conv_stagger;
-        if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
-        if (!q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
-        f.B = q.B; f.H = q.Hin; f.W = q.Win;
-        f.tiles_x = pl.tiles_x; f.tiles_y = pl.tiles_y; f.tiles_per_wg = pl.tiles_per_wg; f.wgs_per_sample = pl.wgs_per_sample;
-        if (nparts) *nparts = f.wgs_per_sample;
-        if (Cs) *Cs = q.cout;
-        HIPCHK(fold_launch(q.cin, f, s));
         return 0;
     }
     ConvArgs a;
@@ -676,7 +618,6 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
     if (q.groups && q.cout % kGroups) return fail("conv: group-format statistics need cout %% 8 == 0");
     a.B = q.B; a.Hin = q.Hin; a.Win = q.Win;
     a.stamps = q.stamps;
-    a.stagger = knobs().conv_stagger;
     a.Hv = pl.Hv; a.Wv = pl.Wv;
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
     a.tiles_per_wg = pl.tiles_per_wg; a.wgs_per_sample = pl.wgs_per_sample;
@@ -951,7 +892,7 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width, M = B * S;
     const float eps = f.fnet_ln_eps;
     const int bf = c->fnet_bf16;
-    const bool dense = c->fx_on && c->fx_packed == packed && knobs().fnet_dense != 0 && knobs().fnet_mix != 0 && fnet_mix_supported(S, hid) &&
+    const bool dense = c->fx_on && c->fx_packed == packed && knobs().fnet_dense != 0 && fnet_mix_supported(S, hid) &&
                        fnet_dense_supported(S, hid, inter) && fnet_dense_supported(S, inter, hid) && fnet_dense_supported(S, width, hid) &&
                        fnet_dense_supported(S, hid, width);
     HIPCHK(layernorm_launch(c->dtype, x, tb->posenc, S, pf(c, packed, c->ln0_w), pf(c, packed, c->ln0_b), eps, w.ln0, M,
@@ -1007,7 +948,7 @@ static int run_fnet(const ddimx_ctx* c, const void* packed, const ddimx_tables* 
         const ddimx_ctx::FL& L = c->fl[i];
         // Ut[b] = D_H * X[b]^T -> [2*hid][S]; D_H rows interleaved (2k: cos_k, 2k+1: sin_k), so that row pair k of
         // Ut[b] is one contiguous K-vector [cos-part(S) | sin-part(S)] for the sequence transform
-        if (fnet_mix_supported(S, hid) && knobs().fnet_mix != 0) {
+        if (fnet_mix_supported(S, hid)) {
             HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, cur, w.Z, B, S, hid, s));
         } else {
         CHK(fnet_gemm(w, s, tb->dft_hidden, cur, w.Ut, 2 * hid, S, hid, hid, hid, S, nullptr, nullptr, 0, 0, 0, B, 0,
@@ -1176,19 +1117,7 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     if ((long long)w.total > workspace_bytes) return fail("workspace too small: need %zu bytes, got %lld", w.total, workspace_bytes);
     hipStream_t s = (hipStream_t)stream, sa = (hipStream_t)aux_stream;
     if (!sa || !events || n_events < 2 || B < 2) fork_mask = 0;
-    // bits 20-23: STAGGER level.  The two shards otherwise run in lock step -- both in the bandwidth-bound shallow levels or both in
-    // the latency-bound middle of the network at the same time.  With a stagger level l (only with every level and the FNet sharded)
-    // shard 1 starts when shard 0 has finished the down path of level l - 1: one shard's deep levels and FNet then run under the
-    // other's level 0-2 convolutions.  Same launches per shard, same results bit for bit; the host enqueues shard 0's whole walk, an
-    // event at the stagger point, then shard 1's walk behind that event (a captured graph gets the edge).
-    int stagger = (int)((fork_mask >> 20) & 0xFu);
     fork_mask &= 0xFFFFFu;
-    {
-        unsigned all = 1u << 16;
-        for (int l = 0; l < L; ++l) all |= 1u << l;
-        if ((fork_mask & all) != all || stagger >= L || n_events < 3) stagger = 0;
-    }
-    int only = -1;  // lane filter of the staggered walk: 0 / 1 = only that shard's launches, -1 = both
     int ev_used = 0;  // every fork and every join records an event of its own: nothing is re-recorded inside one capture
     const int dt = c->dtype;
     const size_t es = esz(dt);
@@ -1216,8 +1145,8 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     auto for_lanes = [&](bool sharded, auto&& op) -> int {
         CHK(sync_for(sharded));
         if (!sharded) return op(Lane{0, B, s});
-        if (only != 0) CHK(op(Lane{bh, B - bh, sa}));
-        if (only != 1) CHK(op(Lane{0, bh, s}));
+        CHK(op(Lane{bh, B - bh, sa}));
+        CHK(op(Lane{0, bh, s}));
         return 0;
     };
     auto at = [&](const void* p, size_t per_sample, int b0) { return (void*)((char*)const_cast<void*>(p) + per_sample * b0); };
@@ -1246,8 +1175,6 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
         });
     };
 
-    hipEvent_t stag_ev = nullptr;
-    auto walk = [&]() -> int {
     cur = 0;
     // ---- down path (models/diffusion.py:252-264) ----
     const size_t in_per = (size_t)f.in_channels * T * f.f_size;  // fp32 NCHW elements per sample at the network boundary
@@ -1261,11 +1188,6 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
     int bi = 0;
     for (int l = 0; l < L; ++l) {
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
-        if (only == 0 && l == stagger && l > 0) {  // shard 0 is done with the down path of level l - 1: shard 1 may start
-            if (ev_used >= n_events) return fail("ddimx_unet_fwd_forked: no event left for the stagger point");
-            stag_ev = (hipEvent_t)events[ev_used++];
-            HIPCHK(hipEventRecord(stag_ev, s));
-        }
         if (l > 0) {
             CHK(for_lanes(lvl_on(l), [&](const Lane& ln) -> int {
                 ConvCall d = {dt, DOWN4, f.ch[l - 1], C, at(xcur, act_bytes(l - 1), ln.b0), pv(c, packed, c->down_w[l]),
@@ -1339,19 +1261,6 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
                                pf(c, packed, c->out_b), eps + in_per * ln.b0, ln.n, f.ch[0], f.in_channels, T, f.f_size, ln.st));
         return 0;
     }));
-    return 0;
-    };  // walk
-    if (stagger > 0) {
-        only = 0;
-        CHK(walk());
-        if (!stag_ev) return fail("ddimx_unet_fwd_forked: stagger point not reached");
-        HIPCHK(hipStreamWaitEvent(sa, stag_ev, 0));
-        only = 1;
-        CHK(walk());
-        only = -1;
-    } else {
-        CHK(walk());
-    }
     CHK(sync_for(false));  // leave with everything joined into `stream`
     return 0;
 }
@@ -1557,7 +1466,7 @@ static int tgemm(const TrainWs& w, hipStream_t s, const float* A, const float* B
 static int fourier_mix(const ddimx_ctx* c, const ddimx_tables* tb, const TrainWs& w, const float* X, float* Z, int B, int S,
                        hipStream_t s) {
     const int hid = c->cfg.fnet_hidden;
-    if (fnet_mix_supported(S, hid) && knobs().fnet_mix != 0) {
+    if (fnet_mix_supported(S, hid)) {
         HIPCHK(fnet_mix_launch(tb->dft_hidden, tb->dft_seq, X, Z, B, S, hid, s));
         return 0;
     }
@@ -2090,15 +1999,6 @@ int ddimx_conv3x3_fwd(int dtype, int C, const void* x, const void* w, const floa
     ConvCall k = {dtype, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
-int ddimx_conv3x3_fold_fwd(int C, const void* x, const void* w, const float* bias, const float* chan_add, int chan_add_stride,
-                           const float* in_scale, const float* in_shift, int act, void* y, float* stats, int B, int H, int W, void* stream) {
-    ConvCall k = {DT_BF16, CONV3, C, C, x, w, bias, chan_add, chan_add_stride, in_scale, in_shift, XF_AFFINE, act, nullptr, y, stats, B, H, W};
-    k.force_fold = true;
-    ConvPlan pl;
-    CHK(conv_plan(k, &pl));
-    if (!pl.fold) return fail("ddimx_conv3x3_fold_fwd: C=%d %dx%d is not eligible for the folded-affine kernel", C, H, W);
-    return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
-}
 static unsigned long long* g_debug_stamps = nullptr;
 int ddimx_debug_set_stamps(unsigned long long* stamps) { g_debug_stamps = stamps; return 0; }  // diagnostic builds: next conv launches stamp here
 int ddimx_pack_conv_frag(const float* w, void* dst, int O, int I, void* stream) {
@@ -2134,19 +2034,23 @@ int ddimx_upsample_add_wreg_fwd(int Cin, int Cout, const void* x, const void* w_
     if (!pl.wreg) return fail("ddimx_upsample_add_wreg_fwd: %d->%d %dx%d is not eligible for the register-streamed kernel", Cin, Cout, H, W);
     return run_conv(u, (hipStream_t)stream, nullptr, nullptr);
 }
-int ddimx_conv3x3_ws_fwd(int C, const void* x, const void* w_frag, const float* bias, const float* chan_add, int chan_add_stride,
-                         const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats, int B, int H, int W,
-                         void* stream) {
-    ConvCall k = {DT_BF16, CONV3, C, C, x, nullptr, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, act, nullptr, y, stats, B, H, W};
+int ddimx_conv3x3_pipe_fwd(int C, const void* x, const void* w_frag, const float* bias, const float* chan_add, int chan_add_stride,
+                           const float* in_scale, const float* in_shift, int xf, void* y, float* group_stats, int B, int H, int W,
+                           void* stream) {
+    ConvCall k = {DT_BF16, CONV3, C, C, x, nullptr, bias, chan_add, chan_add_stride, in_scale, in_shift, xf, 1, nullptr, y, group_stats, B, H, W};
     k.wf = w_frag;
+    k.groups = true;
     k.kernel_pref = 2;
-    k.stamps = g_debug_stamps;
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
-long long ddimx_conv3x3_ws_stats_floats(int C, int B, int H, int W) {
-    WsGeom g;
-    if (ws_geometry(C, &g) != hipSuccess || H % g.th || W % g.tw) return -1;
-    return (long long)B * cdiv((H / g.th) * (W / g.tw), g.tiles_per_wg) * C * 2;
+long long ddimx_conv3x3_pipe_stats_floats(int C, int B, int H, int W) {
+    ConvCall k = {DT_BF16, CONV3, C, C, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, XF_AFFINE, 1, nullptr, nullptr, nullptr, B, H, W};
+    k.wf = &k;  // (any non-null value: only the plan is asked for)
+    k.groups = true;
+    k.kernel_pref = 2;
+    ConvPlan pl;
+    if (conv_plan(k, &pl)) return -1;
+    return (long long)B * pl.wgs_per_sample * kGnSlab;
 }
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats,
@@ -2167,7 +2071,6 @@ int ddimx_debug_conv3x3_stamps(int dtype, int C, const void* x, const void* w, c
     static const int xf = getenv("DDIMX_STAMP_XF") ? atoi(getenv("DDIMX_STAMP_XF")) : XF_AFFINE_SILU;
     ConvCall k = {dtype, CONV3, C, C, x, w, nullptr, chan_add, C, in_scale, in_shift, xf, 1, nullptr, y, stats, B, H, W};
     k.stamps = stamps;
-    k.force_fold = xf == XF_AFFINE && getenv("DDIMX_CONV_FOLD") == nullptr;
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
 long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W) {

@@ -68,8 +68,6 @@ struct ConvArgs {
     int tiles_per_wg;       // consecutive tiles (x-major) walked by one workgroup
     int wgs_per_sample;     // ceil(tiles_x*tiles_y / tiles_per_wg); grid.x = B * wgs_per_sample
     unsigned long long* stamps;  // diagnostic builds only (-DDDIMX_STAMP): [grid.x][16] per-phase cycle sums
-    int stagger;            // > 0: a workgroup that is not the first resident one of its CU (LDS base != 0) sleeps stagger x 1024
-                            // cycles before its prologue, so that the CU's workgroups do not run their phases in lock-step
 };
 
 template <typename T, int CIN_, int NOUT_, int NB_, int MODE_, int TH_, int TW_, int WM_, int WN_, int KC_, int TPC_, int OVL_ = 0, int BWD_ = 0>
@@ -207,14 +205,6 @@ __global__ void __launch_bounds__(C::NTHREADS, C::MINW) conv_mfma_kernel(const C
     float* const gnscr = (float*)(smem + C::LDS_RAW - C::GN_BYTES);
 
     DDIMX_STAMP_ENTRY
-    if (a.stagger > 0) {  // uniform
-        unsigned la;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
-        if (la & 0xffu) {  // LDS_BASE != 0: another workgroup of this CU was placed first
-#pragma unroll 1
-            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % C::WM, wn = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;

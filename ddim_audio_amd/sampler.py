@@ -21,39 +21,25 @@ def _selected(select_index, index, n):
     return select_index is None or index in select_index or index - n in select_index
 
 
-def _default_branches(batch):
-    """Concurrent launch branches for a batch (DDIMX_BRANCHES overrides).  Every op of the path is per sample and the
-    launch plan depends on the sample's size only (a sample's result is bit-identical in any batch), so the batch can be cut
-    into contiguous shards that run the same step on separate HIP streams: the under-filled launches of one shard (GroupNorm
-    finalisation, the FNet's small GEMMs, levels 3-5 at small batches) overlap the other shard's full-chip convolutions."""
-    env = os.environ.get("DDIMX_BRANCHES")
-    if env:
-        return max(1, min(int(env), batch))
-    # default since the in-library fork (ddimx_unet_fwd_forked: shards only where they pay, the latency-bound deep levels stay
-    # whole-batch launches): one branch here.  Whole-step branches remain available (DDIMX_BRANCHES=2) for comparison.
-    return 1
-
-
 class DDIMStepper:
     """One sampling run's device state and its step function.
 
     ``step()`` = reference ``functions/denoising.py:22-43`` for one iteration: timestep fill, model
     forward, fused x0-prediction + x_{t-1} update, counter advance.  The scalars come from a device
     table indexed by a device counter, so after the first (eager) step the same launch sequence is
-    captured once into a hipGraph and replayed for every later step.  The batch is cut into ``branches``
-    contiguous shards, each enqueued on its own stream between a fork and a join (parallel branches of the
-    captured graph); results do not depend on the cut (see ``_default_branches``).
+    captured once into a hipGraph and replayed for every later step.  (The two batch shards on two streams live inside the
+    library call, ``ddimx_unet_fwd_forked``: the captured graph has two parallel branches.)
 
     Ownership.  The captured graph holds raw pointers into the model's packed weights, embedding table,
     DFT / positional tables and workspaces, into this object's ``xt`` / ``x0`` / ``eps`` / ``t`` / ``coef`` / ``counter``,
     and its capture recorded the fork / join events of ``ForkContext``.  All of these are referenced from HERE for as long as
     the graph exists (``_refs``, ``_ctx``), the graph is destroyed FIRST (``close``), and a replay is refused -- the step
     falls back to eager launches and re-captures -- when the model has re-allocated any of those buffers since the capture
-    (``Model._gen``) or needs a repack (``Model._dirty``).  Nothing is allocated on a side stream or inside the capture:
-    workspaces of all shards are reserved and the eps buffer is allocated on the launch stream before the fork.
+    (``Model._gen``); a repack (new parameter values) is carried out in place before the replay.  Nothing is allocated on a
+    side stream or inside the capture: the workspace is reserved and the eps buffer allocated on the launch stream before.
     """
 
-    def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None, branches=None):
+    def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None):
         self.graph = None          # first attribute: close() / __del__ must find it whatever else failed
         self._ctx = self._refs = None
         self.lib = _lib.load()
@@ -71,67 +57,47 @@ class DDIMStepper:
         self.captures = 0
         self._capture_pending = self.use_graph
         self._gen = None
-        from .dist import shard_bounds
         self.native = hasattr(model, "forward_slot")  # ddim_audio_amd.Model; anything else is called as model(x, t)
-        nb = branches if branches is not None else _default_branches(xt.size(0))
-        if not self.native:
-            nb = 1
-        nb = max(1, min(nb, xt.size(0)))
-        self.bounds = [shard_bounds(xt.size(0), r, nb) for r in range(nb)]
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(nb - 1)]
         self.eps = torch.empty_like(xt) if self.native else None  # the forward writes here: no allocation per step
 
-    def _branch(self, k, noise):
+    def _prepare(self):
+        """On the launch stream: weight packing (a no-op unless a parameter changed), tables, the workspace."""
+        if self.native:
+            dev, t_len = self.xt.device, self.xt.size(2)
+            self.model.prepare(dev, t_len)
+            self.model.reserve(dev, self.xt.size(0), t_len, 0)
+
+    def _launch(self, noise):
         lib, st = self.lib, _lib.stream()
-        lo, hi = self.bounds[k]
-        xt, t, x0 = self.xt[lo:hi], self.t[lo:hi], self.x0[lo:hi]
+        xt, t, x0 = self.xt, self.t, self.x0
         _lib.check(lib.ddimx_step_begin(_lib.ptr(self.coef), _lib.ptr(self.counter), _lib.ptr(t), t.numel(), st))
         if self.native:
-            et = self.model(xt, t, _slot=k, _fork=(len(self.bounds) == 1), _ctx=self._ctx, _out=self.eps[lo:hi])
+            et = self.model(xt, t, _ctx=self._ctx, _out=self.eps)
         else:
             et = self.model(xt, t)
             if et.dtype != torch.float32 or not et.is_contiguous():
                 et = et.float().contiguous()
-        nz = None if noise is None else noise[lo:hi]
-        _lib.check(lib.ddimx_ddim_update(_lib.ptr(xt), _lib.ptr(et), _lib.ptr(nz), _lib.ptr(x0), _lib.ptr(self.coef),
+        _lib.check(lib.ddimx_ddim_update(_lib.ptr(xt), _lib.ptr(et), _lib.ptr(noise), _lib.ptr(x0), _lib.ptr(self.coef),
                                          _lib.ptr(self.counter), xt.numel(), st))
-
-    def _prepare(self):
-        """On the launch stream, before any fork: weight packing, tables, the workspaces of every shard."""
-        if self.native:
-            dev, t_len = self.xt.device, self.xt.size(2)
-            self.model.prepare(dev, t_len)
-            for k, (lo, hi) in enumerate(self.bounds):
-                self.model.reserve(dev, hi - lo, t_len, k)
-
-    def _launch(self, noise):
-        main = torch.cuda.current_stream(self.xt.device)
-        for s in self.side:                      # fork
-            s.wait_stream(main)
-        for k in range(1, len(self.bounds)):
-            with torch.cuda.stream(self.side[k - 1]):
-                self._branch(k, noise)
-        self._branch(0, noise)
-        for s in self.side:                      # join
-            main.wait_stream(s)
-        _lib.check(self.lib.ddimx_step_end(_lib.ptr(self.counter), _lib.stream()))
+        _lib.check(lib.ddimx_step_end(_lib.ptr(self.counter), st))
 
     def rewind(self):
         """Restart the coefficient table (benchmark loops longer than the schedule)."""
         self.counter.zero_()
 
     def _stale(self):
-        """Before a replay.  A pending repack (optimizer step, load_state_dict, EMA swap-in, invalidate()) is carried out
-        first, on the launch stream: packed weights and the embedding table are rebuilt IN PLACE, so the graph stays valid
-        and sees the new weights.  The graph is stale only if a buffer it points at was re-allocated since the capture
-        (``Model._gen``: .to() / .type(), another T, a larger batch in the same slot) or the model left eval mode."""
+        """Before a replay.  ``_prepare`` runs the model's own staleness test -- (data_ptr, version) of every parameter, the
+        same key the eager forward uses -- so an optimizer step, ``load_state_dict`` (also the plain nn.Module one), an in-place
+        ``p.copy_()``, an EMA swap-in or ``invalidate()`` repack the weights and the embedding table IN PLACE on the launch
+        stream: the graph stays valid and the replay sees the new values.  (Host work of a replay loop that is otherwise idle:
+        the GPU step takes milliseconds.)  The graph is stale only if a buffer it points at was re-allocated since the capture
+        (``Model._gen``: .to() / .type(), another T, a larger batch) or the model left eval mode."""
         if not self.native:
             return False
         m = self.model
         if m.training:
             return True
-        if m._dirty:
-            self._prepare()
+        self._prepare()
         return m._gen != self._gen
 
     def _drop_graph(self):
@@ -155,7 +121,7 @@ class DDIMStepper:
 
     def _capture(self):
         dev = self.xt.device
-        if self.native and len(self.bounds) == 1 and self.model.fork_mask and self.xt.size(0) >= 4:
+        if self.native and self.model.fork_mask and self.xt.size(0) >= 4:
             self._ctx = self.model.new_fork_context(dev)  # created (and first recorded) eagerly, owned here
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()

@@ -209,12 +209,6 @@ long long ddimx_conv3x3_stats_floats(int dtype, int C, int B, int H, int W);
  * ddimx_unet_fwd launches for the Residual_Block convs (models/diffusion.py:46-53) of those widths; fails if the shape is not
  * eligible (ddimx_conv3x3_fwd is the general entry). */
 int ddimx_pack_conv_frag(const float* w, void* dst, int O, int I, void* stream);
-/* conv1(GN1(h)) + bias (+ SiLU) of Residual_Block (models/diffusion.py:49-53) through the folded-affine kernel (csrc/conv_fold.h:
- * the GroupNorm affine folded into per-workgroup weights, the halo by LDS-DMA; bf16, C = 32, whole 8x32 tiles).  An alternative
- * to ddimx_conv3x3_fwd(xf = 1) kept for A/B (DDIMX_CONV_FOLD=1 puts it into the network walk); w as for ddimx_conv3x3_fwd. */
-int ddimx_conv3x3_fold_fwd(int C, const void* x, const void* w, const float* bias, const float* chan_add, int chan_add_stride,
-                           const float* in_scale, const float* in_shift, int act, void* y, float* stats, int B, int H, int W,
-                           void* stream);
 /* Diagnostic builds (-DDDIMX_STAMP) only: ddimx_conv3x3_wreg_fwd writes its per-wave phase stamps here (null: off). */
 int ddimx_debug_set_stamps(unsigned long long* stamps);
 /* The same for any tap count (KK = KH * KW; Downsample: 16), and Downsample.forward (models/diffusion.py:70-78) through the
@@ -229,14 +223,16 @@ int ddimx_downsample_wreg_fwd(int Cin, int Cout, const void* x, const void* w_fr
 int ddimx_pack_frag_from_taps(const void* taps, void* dst, int ntaps, int NOUT, int CIN, void* stream);
 int ddimx_upsample_add_wreg_fwd(int Cin, int Cout, const void* x, const void* w_frag, const float* bias2, const void* skip, void* y,
                                 float* stats, int B, int H, int W, void* stream);
-/* The same two convolutions through the wave-specialised kernel (csrc/conv_ws.h: MFMA waves multiply tile t while loader waves
- * fetch + transform the halo of tile t + 1 and drain the output of tile t - 1; C = 32 / 64, whole tiles of the configuration);
- * arguments as ddimx_conv3x3_wreg_fwd without the LDS-layout weights.  stats: per-channel (sum, sumsq) partials
- * [B][workgroups per sample][C][2], ddimx_conv3x3_ws_stats_floats floats (-1: shape not eligible). */
-int ddimx_conv3x3_ws_fwd(int C, const void* x, const void* w_frag, const float* bias, const float* chan_add, int chan_add_stride,
-                         const float* in_scale, const float* in_shift, int xf, int act, void* y, float* stats, int B, int H, int W,
-                         void* stream);
-long long ddimx_conv3x3_ws_stats_floats(int C, int B, int H, int W);
+/* Both convs of Residual_Block (models/diffusion.py:46-53: conv(SiLU(GN(x))) + temb -> SiLU, conv(GN(h)) + bias -> SiLU) through
+ * the software-pipelined kernel (csrc/conv_pipe.h: weights resident in registers, the next tile's halo transform and the previous
+ * block's epilogue issued in the MFMA gaps of the same wave; bf16, C = 32 / 64, H and W whole numbers of its tiles) -- what
+ * ddimx_unet_fwd launches for those widths.  xf = 1 (affine input) or 2 (affine + SiLU); the output activation is SiLU.
+ * group_stats: [B][workgroups per sample][32] floats = 8 groups x (sum, sum of squares) of the fp32 values before the bf16
+ * rounding + zero padding (gn_fused.h), ddimx_conv3x3_pipe_stats_floats floats (-1: shape not eligible); nullable. */
+int ddimx_conv3x3_pipe_fwd(int C, const void* x, const void* w_frag, const float* bias, const float* chan_add, int chan_add_stride,
+                           const float* in_scale, const float* in_shift, int xf, void* y, float* group_stats, int B, int H, int W,
+                           void* stream);
+long long ddimx_conv3x3_pipe_stats_floats(int C, int B, int H, int W);
 int ddimx_conv3x3_wreg_fwd(int C, const void* x, const void* w, const void* w_frag, const float* bias, const float* chan_add,
                            int chan_add_stride, const float* in_scale, const float* in_shift, int xf, int act, void* y,
                            float* stats, int B, int H, int W, void* stream);

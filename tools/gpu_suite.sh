@@ -1,11 +1,11 @@
 #!/bin/bash
 # The GPU test suite, once, in one process, with a log that no later run overwrites.
 #   gpurun --timeout 1200 -- 'bash tools/gpu_suite.sh [extra pytest args]'
-# stdout+stderr (faulthandler dumps, AMD_LOG_LEVEL=1 messages of the HIP runtime) -> gpurun_out/r03/gputest_<time>.log;
+# stdout+stderr (faulthandler dumps, AMD_LOG_LEVEL=1 messages of the HIP runtime) -> gpurun_out/r04/gputest_<time>.log;
 # tests/conftest.py adds gpurun_out/crash/<time>_<pid>.txt with one flushed line per test start.
 set -o pipefail
-mkdir -p gpurun_out/r03
-log=gpurun_out/r03/gputest_$(date +%Y%m%d_%H%M%S).log
+mkdir -p gpurun_out/r04
+log=gpurun_out/r04/gputest_$(date +%Y%m%d_%H%M%S).log
 export AMD_LOG_LEVEL=${AMD_LOG_LEVEL:-1}
 export PYTHONFAULTHANDLER=1
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q -p no:cacheprovider "$@" > "$log" 2>&1

@@ -15,7 +15,7 @@ import sys
 csv.field_size_limit(1 << 30)
 
 
-def load_pass(d, want=("conv_mfma_kernel", "conv3_fold_kernel", "conv3_wreg_kernel")):
+def load_pass(d, want=("conv_mfma_kernel", "conv3_pipe_kernel", "conv3_wreg_kernel")):
     vals, dur = {}, {}
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):

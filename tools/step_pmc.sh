@@ -14,7 +14,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 dur = collections.defaultdict(float); cnt = collections.defaultdict(int); seen = set()
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    m = re.search(r"(conv3_wreg_kernel<ddimx::WregCfg<\d+)|(conv3_fold)|(ConvCfgIDF16bLi\d+ELi\d+ELi\d+ELi\d)|(resid_kernel)|(gemm_nt)|(fnet_mix2)|(fnet_dense_kernel<[^>]*>)|(fnet_mix)|(gemm_splitk)|(layernorm)|(gemm_reduce_ln)|(conv_out)|(conv_in)", n)
+    m = re.search(r"(conv3_wreg_kernel<ddimx::WregCfg<\d+)|(conv3_pipe_kernel<ddimx::PipeCfg<\d+, \d+, \d+, \d)|(ConvCfgIDF16bLi\d+ELi\d+ELi\d+ELi\d)|(resid_kernel)|(gemm_nt)|(fnet_mix2)|(fnet_dense_kernel<[^>]*>)|(fnet_mix)|(gemm_splitk)|(layernorm)|(gemm_reduce_ln)|(conv_out)|(conv_in)", n)
     key = m.group(0) if m else n[:40]
     agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
     did = r["Dispatch_Id"]
