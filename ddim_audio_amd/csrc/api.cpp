@@ -31,7 +31,11 @@ struct Knobs {
         gn_dbg = geti("DDIMX_GN_DBG", 0);          // tools/gn_dbg.sh: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
         fnet_dense = geti("DDIMX_FNET_DENSE", 1);  // tools/fnet_ab.sh: 0 = the GEMM path for the FNet at S <= 32
         conv_wreg = geti("DDIMX_CONV_WREG", 1);    // tools/step_ab.sh: 0 = the convs of C >= 64 keep the LDS weight ring (conv_mfma_kernel)
-        conv_pipe = geti("DDIMX_CONV_PIPE", 1);    // tools/step_ab.sh: 0 = levels 0-1 keep conv_mfma_kernel / conv3_wreg_kernel
+        // conv3_pipe_kernel in the walk, bit 0: C = 32, bit 1: C = 64.  Default: level 0 only.  With the two batch shards in flight the
+        // C = 64 form (one four-wave workgroup per CU: 144 registers of weights per wave) runs its B = 4 launches on half the chip,
+        // 51-63 us against conv3_wreg_kernel's 43 (profiles/r04/pipe_v2_forked_step_kernels.txt); alone on the chip it is level
+        // (58 / 65 vs 57 / 67 us at B = 8) and in the single-stream step it wins (DDIMX_FORK_MASK=0: +5.5 % with both levels on).
+        conv_pipe = geti("DDIMX_CONV_PIPE", 1);
         pipe_tpw = geti("DDIMX_PIPE_TPW", 0);      // tools/pipe_time.py: tiles per workgroup of conv3_pipe_kernel
     }
 };
@@ -485,7 +489,7 @@ struct ConvPlan { ConvGeom g; int var, Hv, Wv, tiles_x, tiles_y, tiles_per_wg, w
 // for (C = 32, 64): bf16, GroupNorm-affine (+ SiLU) input, SiLU output, group-format statistics, fragment-order weights, whole
 // tiles.  The choice depends on the sample's size only (never on the batch).
 static bool pipe_eligible(const ConvCall& q, PipeGeom* pg) {
-    if (q.kernel_pref == 1 || !(knobs().conv_pipe || q.kernel_pref == 2)) return false;
+    if (q.kernel_pref == 1 || !((knobs().conv_pipe >> (q.cin == 32 ? 0 : 1)) & 1 || q.kernel_pref == 2)) return false;  // bit 0: C = 32, bit 1: C = 64
     if (!q.wf || q.dtype != DT_BF16 || q.mode != CONV3 || q.cin != q.cout || q.act != 1 || q.aux || q.bwd_mode || q.skip || q.batch_plan || g_batch_plan)
         return false;
     if (q.xf != XF_AFFINE && q.xf != XF_AFFINE_SILU) return false;
@@ -515,10 +519,10 @@ static int conv_plan(const ConvCall& q, ConvPlan* p) {
         p->tiles_x = q.Win / pgm.tw;
         p->tiles_y = q.Hin / pgm.th;
         const int tiles_s = p->tiles_x * p->tiles_y;
-        // one workgroup per CU, persistent: 32 workgroups per T = 1024 sample (16 tiles at C = 32, 8 at C = 64), so that a batch of 8
-        // -- or its two shards of 4 on two streams -- is one round of 256 workgroups; long samples keep the tile count per workgroup
-        int tpw = q.cin == 32 ? 16 : 8;
-        if (const int v = knobs().pipe_tpw; v > 0) tpw = v;
+        // persistent workgroups of 8 tiles: C = 32 (8 x 32 tiles, two workgroups per CU): 128 workgroups per T = 1024 sample, a shard of
+        // four samples = one round of 512; C = 64 (one workgroup per CU): 32 per sample.  Long samples keep the tile count per workgroup
+        int tpw = 8;
+        if (const int v = knobs().pipe_tpw; v > 0) tpw = q.cin == 32 ? (v & 0xff) : ((v >> 8) ? (v >> 8) : tpw);  // tuning: L0 | L1 << 8
         if (tpw > tiles_s) tpw = tiles_s;
         p->tiles_per_wg = tpw;
         p->wgs_per_sample = cdiv(tiles_s, tpw);
@@ -596,6 +600,9 @@ static int run_conv(const ConvCall& q, hipStream_t s, int* nparts, int* Cs) {
         f.in = q.in; f.wf = q.wf; f.skip = q.skip; f.bias = q.bias; f.chan_add = q.chan_add; f.chan_add_stride = q.chan_add_stride;
         f.in_scale = q.in_scale; f.in_shift = q.in_shift; f.gn = q.gn; f.out = q.out; f.stats = q.stats;
         f.stats_groups_c = q.groups ? q.cout : 0; f.xf = q.xf; f.act = q.act; f.stamps = q.stamps;
+#ifdef DDIMX_STAMP
+        { static const int dbg = getenv("DDIMX_PIPE_DBG") ? atoi(getenv("DDIMX_PIPE_DBG")) : 0; f.dbg = dbg; }
+#endif
         if (q.gn.stats && q.gn.np > kGnFuseMaxParts) return fail("conv: %d statistics partials per sample cannot be finished in-kernel", q.gn.np);
         if (q.xf != XF_NONE && !q.gn.stats && (!q.in_scale || !q.in_shift)) return fail("conv: affine input without scale / shift");
         f.B = q.B; f.H = q.Hin; f.W = q.Win;
@@ -2041,6 +2048,7 @@ int ddimx_conv3x3_pipe_fwd(int C, const void* x, const void* w_frag, const float
     k.wf = w_frag;
     k.groups = true;
     k.kernel_pref = 2;
+    k.stamps = g_debug_stamps;
     return run_conv(k, (hipStream_t)stream, nullptr, nullptr);
 }
 long long ddimx_conv3x3_pipe_stats_floats(int C, int B, int H, int W) {

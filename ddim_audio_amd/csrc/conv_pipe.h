@@ -42,9 +42,10 @@ __device__ __forceinline__ void static_for(Fn&& f) {
     }
 }
 
-template <int C_, int TH_, int WM_, int XF_, int MINW_ = 1>
+template <int C_, int TH_, int WM_, int XF_, int MINW_ = 1, int DBG_ = 0>
 struct PipeCfg {
     static constexpr int C = C_, TH = TH_, TW = 32, WM = WM_, XF = XF_, MINW = MINW_;
+    static constexpr int DBG = DBG_;  // diagnostic builds only: 1 = no MFMAs, 2 = no XF stage, 4 = no EPI stage (timing of the rest; results are garbage)
     static constexpr int WN = C / 32;                    // one 32-cout block per wave
     static constexpr int NBLK = C / 32;
     static constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
@@ -63,22 +64,27 @@ struct PipeCfg {
     static constexpr int OFF_TR = 2 * HALO_BYTES, OFF_DUMP = OFF_TR + NWAVES * TR_BYTES, OFF_GN = OFF_DUMP + DUMP_BYTES;
     static constexpr int LDS_BYTES = OFF_GN + GN_BYTES + 256;
     static constexpr int PD = 2, NBQ = 3;                // B operands are read PD steps ahead into a ring of NBQ
-    // Work items, one per step at most of each kind, so that the scheduler always has FOUR independent dependency chains to
-    // interleave behind an MFMA (a single wave per SIMD stalls on every dependent transcendental otherwise):
-    //   EPI quad q of the previous block (4 accumulator elements -> one 8-byte LDS write) at step E0 + q * EQ of a block, the LDS
-    //   read-back at ER, the two global stores at ES;
-    //   XF half-piece i (4 elements; the second half packs, writes and re-loads) at step XSTEP(i) of the tile.
-    static constexpr int E0 = 3, EQ = (NSTEP - 8) / 5, ER = E0 + 3 * EQ + 2, ES = ER + 4;
-    static constexpr int NXH = 2 * HPT;
-    static constexpr int xstep(int i) { return ((2 * i + 1) * NS_TILE) / (2 * NXH); }
+    // Work units of the two filler stages.  A wave issues one instruction per ~4.75 cycles of any kind (transcendentals 8.3); five
+    // scalar vector instructions hide in the wave's own MFMA (32.6 cycles), an MFMA costs the stream ~9 (tools/dbg/mfma_valu_overlap.hip,
+    // profiles/r04/mfma_valu_overlap_microbench.txt).  A transcendental result needs one independent instruction before its consumer
+    // (else hipcc pads with s_nop): every unit is cut in two phases EP steps apart, phase b of one unit sharing its step with phase a
+    // of the next, XF and EPI units sharing steps, so that the scheduler always has independent chains to interleave.
+    //   XF unit u = (piece u / 4, word u % 4): two elements -> one packed word (a: unpack, affine, exp; b: rcp, product, pack; the
+    //   piece's last unit also zeroes / writes / re-loads);   XPB units per block at block steps E0 + j * EP (+ EP)
+    //   EPI unit e = (quad e / 2, half e % 2) of the PREVIOUS block: two accumulator elements -> one packed word (a: exp; b: rcp,
+    //   product, statistics, pack; the quad's second unit writes 8 bytes to the transposition buffer) at block steps E0 + e * EP
+    //   (+ EP); the read-back at ER, the two global stores at ES.
+    static constexpr int NXU = 4 * HPT, XPB = (NXU + MT - 1) / MT;
+    static constexpr int E0 = 2, EP = (NSTEP - 6) / (XPB > 8 ? XPB : 8) > 0 ? (NSTEP - 6) / (XPB > 8 ? XPB : 8) : 1;
+    static constexpr int ER = E0 + 8 * EP + 2, ES = ER + 3;   // (phase b of a unit runs EP steps after its phase a: beside phase a of the next)
+    static constexpr int xstep(int u) { return (u / XPB) * NSTEP + E0 + (u % XPB) * EP; }
     static_assert(C == 32 || C == 64, "widths whose weight fragments fit the register file next to everything else");
     static_assert(TH % WM == 0 && MT % 2 == 0, "blocks per wave must be even (two alternating accumulators across tiles)");
     static_assert(NTHREADS % LPP == 0 && NTHREADS <= 1024, "thread map");
     static_assert(HPT <= 16, "validity masks are 16 bits");
     static_assert(HALO_BYTES + 16 <= 65536, "LDS immediates");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(EQ >= 1 && ER < ES && ES < NSTEP, "epilogue schedule");
-    static_assert(NS_TILE >= NXH, "one XF half-piece per step at most");
+    static_assert(ER < ES && ES < NSTEP && E0 + XPB * EP < NSTEP, "filler schedule");
 };
 
 template <class F>
@@ -91,6 +97,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
     char* const dump = smem + F::OFF_DUMP;
     float* const gnscr = (float*)(smem + F::OFF_GN);
 
+    DDIMX_STAMP_ENTRY
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % F::WM, wn = wave / F::WM;
@@ -177,8 +184,8 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
         return (x | (x >> 16)) & 0xFFFFu;
     };
 
-    // ---- GroupNorm input: folded (scale, shift) of this thread's 8 channels; for SiLU also their -log2(e) multiples ----------------
-    float sc[8], sh[8], sc2[8], sh2[8];
+    // ---- GroupNorm input: folded (scale, shift) of this thread's 8 channels -----------------------------------------------------------
+    float sc[8], sh[8];
     {
         const bool gn_fused = a.gn.stats != nullptr;  // uniform
         GnInLoads gn_ld;
@@ -201,8 +208,6 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
 #pragma unroll
             for (int j = 0; j < 8; ++j) { sc[j] = fs[j]; sh[j] = fh[j]; }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sc2[j] = sc[j] * kNegLog2e; sh2[j] = sh[j] * kNegLog2e; }
     }
 
     // ---- pipeline stage XF: one element / one piece --------------------------------------------------------------------------------
@@ -212,26 +217,29 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
         constexpr int k = decltype(k_)::value, w = decltype(w_)::value;
         return w == 0 ? hreg[k].x : (w == 1 ? hreg[k].y : (w == 2 ? hreg[k].z : hreg[k].w));
     };
-    // four elements of piece k (half = 0: channels 0-3 of the piece, 1: channels 4-7), written stage by stage
-    auto xf_half = [&](auto k_, auto half_) __attribute__((always_inline)) {
-        constexpr int j0 = decltype(half_)::value * 4;
-        const unsigned w0 = word_of(k_, std::integral_constant<int, j0 / 2>()), w1 = word_of(k_, std::integral_constant<int, j0 / 2 + 1>());
-        float x[4], y[4];
-        x[0] = __uint_as_float(w0 << 16); x[1] = __uint_as_float(w0 & 0xffff0000u);
-        x[2] = __uint_as_float(w1 << 16); x[3] = __uint_as_float(w1 & 0xffff0000u);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = fmaf(x[i], sc[j0 + i], sh[j0 + i]);
+    // two elements of piece k (word p: channels 2p, 2p + 1 of the piece) -> one packed word, in two phases (held in xy / xe[p & 1]).
+    // SCALAR f32 arithmetic on purpose: v_pk_*_f32 does not run beside the wave's MFMA (tools/dbg/mfma_valu_overlap.hip: one
+    // v_pk_fma_f32 in an MFMA gap costs the whole gap, +25 cycles, while up to five v_fma_f32 / v_cvt_pk / one v_exp are free)
+    float xy[2][2], xe[2][2];
+    auto xf_a = [&](auto k_, auto p_) __attribute__((always_inline)) {
+        constexpr int p = decltype(p_)::value;
+        const unsigned w0 = word_of(k_, p_);
+        const float x0 = __uint_as_float(w0 << 16), x1 = __uint_as_float(w0 & 0xffff0000u);
+        const float y0 = fmaf(x0, sc[2 * p], sh[2 * p]), y1 = fmaf(x1, sc[2 * p + 1], sh[2 * p + 1]);
+        xy[p & 1][0] = y0; xy[p & 1][1] = y1;
         if constexpr (XF == XF_AFFINE_SILU) {
-            float e[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(fmaf(x[i], sc2[j0 + i], sh2[j0 + i]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(e[i] + 1.0f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] *= e[i];
+            xe[p & 1][0] = __builtin_amdgcn_exp2f(y0 * kNegLog2e);
+            xe[p & 1][1] = __builtin_amdgcn_exp2f(y1 * kNegLog2e);
         }
-        xw[j0 / 2] = Piece<__bf16>::pk(y[0], y[1]);
-        xw[j0 / 2 + 1] = Piece<__bf16>::pk(y[2], y[3]);
+    };
+    auto xf_b = [&](auto k_, auto p_) __attribute__((always_inline)) {
+        constexpr int p = decltype(p_)::value;
+        float y0 = xy[p & 1][0], y1 = xy[p & 1][1];
+        if constexpr (XF == XF_AFFINE_SILU) {
+            y0 *= __builtin_amdgcn_rcpf(xe[p & 1][0] + 1.0f);
+            y1 *= __builtin_amdgcn_rcpf(xe[p & 1][1] + 1.0f);
+        }
+        xw[p] = Piece<__bf16>::pk(y0, y1);
     };
     // zero what lies outside the image (AFTER the transform: the conv pads the normalised tensor), one LDS write; the piece's
     // registers then take the same piece of the tile after next
@@ -257,20 +265,23 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
     const char* const tr_r = trb + wave * F::TR_BYTES + (lane >> 2) * F::TR_STRIDE + (lane & 3) * 16;  // + k * 16 * TR_STRIDE
     const unsigned st_lane = (unsigned)((lane >> 2) * (C * 2) + wn * 64 + (lane & 3) * 16);       // + k * 16 * C * 2
     uint4 trv[2];
-    auto epi_quad = [&](const f32x16_t& acc, auto q_) __attribute__((always_inline)) {
-        constexpr int q = decltype(q_)::value;
-        float v[4], e[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[q * 4 + i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(v[i] * kNegLog2e);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(e[i] + 1.0f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= e[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { st_s[q] += v[i]; st_q[q] = fmaf(v[i], v[i], st_q[q]); }
-        *(uint2*)(tr_w + q * 16) = make_uint2(Piece<__bf16>::pk(v[0], v[1]), Piece<__bf16>::pk(v[2], v[3]));
+    unsigned ow[2];
+    float ev[2][2], ee[2][2];
+    auto epi_a = [&](const f32x16_t& acc, auto e_) __attribute__((always_inline)) {
+        constexpr int e = decltype(e_)::value, q = e / 2, i2 = e % 2;
+        const float v0 = acc[q * 4 + 2 * i2], v1 = acc[q * 4 + 2 * i2 + 1];
+        ev[i2][0] = v0; ev[i2][1] = v1;
+        ee[i2][0] = __builtin_amdgcn_exp2f(v0 * kNegLog2e);
+        ee[i2][1] = __builtin_amdgcn_exp2f(v1 * kNegLog2e);
+    };
+    auto epi_b = [&](auto e_) __attribute__((always_inline)) {
+        constexpr int e = decltype(e_)::value, q = e / 2, i2 = e % 2;
+        const float v0 = ev[i2][0] * __builtin_amdgcn_rcpf(ee[i2][0] + 1.0f);
+        const float v1 = ev[i2][1] * __builtin_amdgcn_rcpf(ee[i2][1] + 1.0f);
+        st_s[q] += v0; st_q[q] = fmaf(v0, v0, st_q[q]);
+        st_s[q] += v1; st_q[q] = fmaf(v1, v1, st_q[q]);
+        ow[i2] = Piece<__bf16>::pk(v0, v1);
+        if constexpr (i2 == 1) *(uint2*)(tr_w + q * 16) = make_uint2(ow[0], ow[1]);
     };
     auto epi_readback = [&]() __attribute__((always_inline)) {
         trv[0] = *(const uint4*)(tr_r);
@@ -278,8 +289,9 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
     };
     auto epi_store = [&](__amdgpu_buffer_rsrc_t orsrc, unsigned rowbase) __attribute__((always_inline)) {
         const u32x4_t t0 = {trv[0].x, trv[0].y, trv[0].z, trv[0].w}, t1 = {trv[1].x, trv[1].y, trv[1].z, trv[1].w};
-        __builtin_amdgcn_raw_buffer_store_b128(t0, orsrc, st_lane, rowbase, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(t1, orsrc, st_lane + 16 * C * 2, rowbase, 0);
+        const unsigned rb = __builtin_amdgcn_readfirstlane(rowbase);  // (wave-uniform; a VGPR here costs a waterfall loop per store)
+        __builtin_amdgcn_raw_buffer_store_b128(t0, orsrc, st_lane, rb, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(t1, orsrc, st_lane + 16 * C * 2, rb, 0);
     };
 
     // ---- prologue: tile 0 transformed outright, tile 1 requested ------------------------------------------------------------------------
@@ -299,8 +311,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
         const unsigned b1 = halo_base(ty2, tx2);
         const unsigned inval_b = halo_inval(ty2, tx2);
         static_for<0, HPT>([&](auto k_) {
-            xf_half(k_, std::integral_constant<int, 0>());
-            xf_half(k_, std::integral_constant<int, 1>());
+            static_for<0, 4>([&](auto p_) { xf_a(k_, p_); xf_b(k_, p_); });
             xf_finish(k_, halo, inval_a, r1, b1);
         });
         inval_a = inval_b;
@@ -315,6 +326,7 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    DDIMX_STAMP_DECL
 
     // ---- the tile body -------------------------------------------------------------------------------------------------------------------
     auto body = [&](auto xfn_, int cur, int t) __attribute__((always_inline)) {
@@ -340,24 +352,32 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
             {
                 f32x16_t& acc = (m & 1) ? acc1 : acc0;
                 const bf16x8_t av = __builtin_bit_cast(bf16x8_t, wfr[s]), bv = __builtin_bit_cast(bf16x8_t, bq[G % F::NBQ]);
-                if constexpr (s == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, addvec, 0, 0, 0);
+                if constexpr (F::DBG & 1) { if constexpr (s == 0) acc = addvec; asm volatile("" :: "v"(av), "v"(bv)); }
+                else if constexpr (s == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, addvec, 0, 0, 0);
                 else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
             }
-            // XF: a half-piece of the next tile's halo
-            if constexpr (XFN) {
-                static_for<0, F::NXH>([&](auto i_) {
-                    constexpr int i = decltype(i_)::value;
-                    if constexpr (F::xstep(i) == G) {
-                        xf_half(std::integral_constant<int, i / 2>(), std::integral_constant<int, i % 2>());
-                        if constexpr (i % 2 == 1) xf_finish(std::integral_constant<int, i / 2>(), hdst, inval_a, r2, b2);
+            // XF: units of the next tile's halo (phase b of the previous unit first: its inputs are a step old)
+            if constexpr (XFN && !(F::DBG & 2)) {
+                static_for<0, F::NXU>([&](auto u_) {
+                    constexpr int u = decltype(u_)::value;
+                    if constexpr (F::xstep(u) + F::EP == G) {
+                        xf_b(std::integral_constant<int, u / 4>(), std::integral_constant<int, u % 4>());
+                        if constexpr (u % 4 == 3) xf_finish(std::integral_constant<int, u / 4>(), hdst, inval_a, r2, b2);
                     }
+                });
+                static_for<0, F::NXU>([&](auto u_) {
+                    constexpr int u = decltype(u_)::value;
+                    if constexpr (F::xstep(u) == G) xf_a(std::integral_constant<int, u / 4>(), std::integral_constant<int, u % 4>());
                 });
             }
             // EPI: the previous block (block MT - 1 of the previous tile for m = 0)
-            {
+            if constexpr (!(F::DBG & 4)) {
                 const f32x16_t& pacc = (m & 1) ? acc0 : acc1;  // (m - 1) & 1, and (MT - 1) & 1 = 1 for m = 0
-                static_for<0, 4>([&](auto q_) {
-                    if constexpr (s == F::E0 + decltype(q_)::value * F::EQ) epi_quad(pacc, q_);
+                static_for<0, 8>([&](auto e_) {
+                    if constexpr (s == F::E0 + (decltype(e_)::value + 1) * F::EP) epi_b(e_);
+                });
+                static_for<0, 8>([&](auto e_) {
+                    if constexpr (s == F::E0 + decltype(e_)::value * F::EP) epi_a(pacc, e_);
                 });
                 if constexpr (s == F::ER) epi_readback();
                 if constexpr (s == F::ES) {
@@ -379,14 +399,17 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
         else body(std::false_type(), cur, t);
         advance(ty, tx);
         advance(ty2, tx2);
+        DDIMX_STAMP_AT(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's halo reads have returned, its halo writes have landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        DDIMX_STAMP_AT(1);
     }
     // ---- drain: the last block's epilogue ----------------------------------------------------------------------------------------------
-    static_for<0, 4>([&](auto q_) { epi_quad(acc1, q_); });
+    static_for<0, 8>([&](auto e_) { epi_a(acc1, e_); epi_b(e_); });
     epi_readback();
     epi_store(prev_rsrc, prev_rowbase);
+    DDIMX_STAMP_AT(2);
 
     // ---- statistics: one group-format slab per workgroup (gn_fused.h) --------------------------------------------------------------------
     if (a.stats) {  // uniform
@@ -424,6 +447,8 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
             a.stats[((size_t)bs * a.wgs_per_sample + wg) * kGnSlab + tid] = tot;
         }
     }
+    DDIMX_STAMP_AT(3);
+    DDIMX_STAMP_FLUSH();
 }
 
 template <class F>

@@ -125,7 +125,9 @@ class DDIMStepper:
             self._ctx = self.model.new_fork_context(dev)  # created (and first recorded) eagerly, owned here
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: only THIS thread's calls are checked against the capture -- other threads of the process (a collective
+        # library's proxy / watchdog threads, a data loader pinning memory) may allocate or free while we capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._launch(None)
         self.graph = g
         self.captures += 1

@@ -25,13 +25,19 @@ scale = torch.rand(B, C, device=dev) + 0.5
 shift = torch.randn(B, C, device=dev) * 0.1
 stats = torch.zeros(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)), device=dev)
 bias = torch.randn(C, device=dev) * 0.1
-wreg = C >= 64 and os.environ.get("DDIMX_ONE_WREG", "1") != "0"  # what the inference walk launches from C = 64 up (csrc/conv_wreg.h)
-if wreg:
+pipe = C <= 64 and os.environ.get("DDIMX_ONE_PIPE", "1") != "0"    # what the inference walk launches at C = 32 / 64 (csrc/conv_pipe.h)
+wreg = C >= 64 and os.environ.get("DDIMX_ONE_WREG", "1") != "0"  # C >= 96 (and the previous kernel of C = 64): csrc/conv_wreg.h
+if wreg or pipe:
     wt = torch.randn(C, C, 3, 3, device=dev) * (1.0 / (9 * C) ** 0.5)
     wf = torch.empty(9 * C * C, dtype=tdt, device=dev)
     _lib.check(lib.ddimx_pack_conv_frag(_lib.ptr(wt), _lib.ptr(wf), C, C, _lib.stream()))
+if pipe:
+    stats = torch.zeros(int(lib.ddimx_conv3x3_pipe_stats_floats(C, B, H, W)), device=dev)
 for _ in range(reps):
-    if wreg:
+    if pipe:
+        _lib.check(lib.ddimx_conv3x3_pipe_fwd(C, _lib.ptr(x), _lib.ptr(wf), None if xf == 2 else _lib.ptr(bias), _lib.ptr(temb) if xf == 2 else None, C,
+                                              _lib.ptr(scale), _lib.ptr(shift), xf, _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+    elif wreg:
         _lib.check(lib.ddimx_conv3x3_wreg_fwd(C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(wf), None if xf == 2 else _lib.ptr(bias),
                                               _lib.ptr(temb) if xf == 2 else None, C, _lib.ptr(scale), _lib.ptr(shift), xf, 1,
                                               _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
@@ -43,3 +49,20 @@ for _ in range(reps):
                                          _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
 torch.cuda.synchronize()
 print("done", float(y.float().abs().mean()))
+if os.environ.get("DDIMX_ONE_TIME"):  # tools/power_probe.sh: a sustained loop, us per launch
+    import time
+    n = int(os.environ["DDIMX_ONE_TIME"])
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(n):
+        if pipe:
+            _lib.check(lib.ddimx_conv3x3_pipe_fwd(C, _lib.ptr(x), _lib.ptr(wf), None if xf == 2 else _lib.ptr(bias), _lib.ptr(temb) if xf == 2 else None, C,
+                                                  _lib.ptr(scale), _lib.ptr(shift), xf, _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+        elif wreg:
+            _lib.check(lib.ddimx_conv3x3_wreg_fwd(C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(wf), None if xf == 2 else _lib.ptr(bias),
+                                                  _lib.ptr(temb) if xf == 2 else None, C, _lib.ptr(scale), _lib.ptr(shift), xf, 1,
+                                                  _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+        else:
+            _lib.check(lib.ddimx_conv3x3_fwd(dt, C, _lib.ptr(x), _lib.ptr(w), None if xf == 2 else _lib.ptr(bias), _lib.ptr(temb) if xf == 2 else None, C,
+                                             _lib.ptr(scale), _lib.ptr(shift), xf, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, _lib.stream()))
+    torch.cuda.synchronize()
+    print("sustained us/launch %.2f over %d launches" % ((time.time() - t0) * 1e6 / n, n))

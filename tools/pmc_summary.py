@@ -43,7 +43,7 @@ def main():
     for lvl in levels:
         c = {}
         durs = {}
-        for p in ("sq1", "sq2", "grbm", "fetch", "write"):
+        for p in ("sq1", "sq2", "sq3", "grbm", "fetch", "write"):
             d = load_pass(os.path.join(root, f"l{lvl}_{p}"))
             if "_dur_ns" in d:
                 durs[p] = d.pop("_dur_ns")
