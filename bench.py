@@ -71,14 +71,20 @@ def per_kernel_times(model, B, T, reps=20):
         stats = torch.empty(int(lib.ddimx_conv3x3_stats_floats(dt, C, B, H, W)) + 2 * B * C * 4096, device=dev)
         st = _lib.stream()
 
+        pipe = bf16 and C == 32  # level 0: the software-pipelined kernel (csrc/conv_pipe.h) -- what the inference walk launches
         wreg = bf16 and C >= 64  # the inference walk's kernel from C = 64 up: weights streamed to registers (csrc/conv_wreg.h)
-        if wreg:
+        if pipe:
+            stats = torch.empty(max(stats.numel(), int(lib.ddimx_conv3x3_pipe_stats_floats(C, B, H, W))), device=dev)
+        if wreg or pipe:
             w_f32 = torch.randn(C, C, 3, 3, device=dev) * (1.0 / (9 * C) ** 0.5)
             wfr = torch.empty(9 * C * C, dtype=tdt, device=dev)
             _lib.check(lib.ddimx_pack_conv_frag(_lib.ptr(w_f32), _lib.ptr(wfr), C, C, st))
 
         def conv():  # K1 of the block: GroupNorm affine + SiLU prologue, + timestep embedding, SiLU
-            if wreg:
+            if pipe:
+                _lib.check(lib.ddimx_conv3x3_pipe_fwd(C, _lib.ptr(x), _lib.ptr(wfr), None, _lib.ptr(temb), C, _lib.ptr(scale), _lib.ptr(shift), 2,
+                                                      _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+            elif wreg:
                 _lib.check(lib.ddimx_conv3x3_wreg_fwd(C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(wfr), None, _lib.ptr(temb), C, _lib.ptr(scale),
                                                       _lib.ptr(shift), 2, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
             else:
@@ -86,7 +92,10 @@ def per_kernel_times(model, B, T, reps=20):
                                                  _lib.ptr(shift), 2, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
 
         def conv2():  # K2 of the block: GroupNorm affine prologue, + bias, SiLU
-            if wreg:
+            if pipe:
+                _lib.check(lib.ddimx_conv3x3_pipe_fwd(C, _lib.ptr(x), _lib.ptr(wfr), _lib.ptr(bias), None, 0, _lib.ptr(scale), _lib.ptr(shift), 1,
+                                                      _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
+            elif wreg:
                 _lib.check(lib.ddimx_conv3x3_wreg_fwd(C, _lib.ptr(x), _lib.ptr(w), _lib.ptr(wfr), _lib.ptr(bias), None, 0, _lib.ptr(scale),
                                                       _lib.ptr(shift), 1, 1, _lib.ptr(y), _lib.ptr(stats), B, H, W, st))
             else:
@@ -100,11 +109,15 @@ def per_kernel_times(model, B, T, reps=20):
         elems = B * H * W * C
         tc1, tc2, tr = timed(conv), timed(conv2), timed(resid)
         tc = 0.5 * (tc1 + tc2)
-        kname = f"conv3_wreg_kernel<bf16,C={C},3x3>" if wreg else f"conv_mfma_kernel<{'bf16' if bf16 else 'f32'},C={C},3x3>"
+        kname = (f"conv3_pipe_kernel<bf16,C={C},3x3>" if pipe else f"conv3_wreg_kernel<bf16,C={C},3x3>" if wreg
+                 else f"conv_mfma_kernel<{'bf16' if bf16 else 'f32'},C={C},3x3>")
         rows.append(dict(kernel=kname, level=lvl, launches_per_fwd=4 * res,
                          seconds=tc, seconds_k1=tc1, seconds_k2=tc2, alg_bytes=2 * elems * es + 9 * C * C * es, flops=2.0 * elems * 9 * C))
         rows.append(dict(kernel=f"resid_kernel<{'bf16' if bf16 else 'f32'},C={C}>", level=lvl, launches_per_fwd=2 * res,
                          seconds=tr, alg_bytes=3 * elems * es, flops=3.0 * elems))
+        # the whole Residual_Block (models/diffusion.py:42-56) = K1 + K2 + resid: 7 activation passes + both weight sets
+        rows.append(dict(kernel=f"Residual_Block<C={C}> (K1 + K2 + resid)", level=lvl, launches_per_fwd=2 * res, block=True,
+                         seconds=tc1 + tc2 + tr, alg_bytes=7 * elems * es + 2 * 9 * C * C * es, flops=2 * 2.0 * elems * 9 * C + 3.0 * elems))
         if lvl > 0:  # Downsample (level lvl-1 -> lvl) and Upsample + skip add (lvl -> lvl-1): models/diffusion.py:59-78,284
             Cp, Hp, Wp = m.ch[lvl - 1], H * 2, W * 2
             xp = torch.randn(B, Hp, Wp, Cp, device=dev).to(tdt)
@@ -252,6 +265,18 @@ def training_leg(args, cfg, dev, rank, world, backend, steps=3):
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dt = float(el.item()) / steps
+        no_overlap_ms = None
+        if world > 1:  # the same step with the gradient all-reduce issued AFTER the backward (no overlap): the staged path's gain
+            from ddim_audio_amd import dist as ddist2
+            ddist2.attach_grad_sync(m, overlap=False)
+            train.train_step(m, x, state, alphas)
+            torch.cuda.synchronize(); dist.barrier()
+            tn = time.perf_counter()
+            for _ in range(steps):
+                train.train_step(m, x, state, alphas)
+            torch.cuda.synchronize(); dist.barrier()
+            no_overlap_ms = (time.perf_counter() - tn) / steps * 1e3
+            ddist2.attach_grad_sync(m)
         ar_ms = None
         if world > 1 and getattr(m, "_flat_grad", None) is not None:  # the step's only collective, timed alone
             torch.cuda.synchronize()
@@ -276,7 +301,7 @@ def training_leg(args, cfg, dev, rank, world, backend, steps=3):
                 gstep.close()
             except Exception as ex:
                 graphed_ms = f"{type(ex).__name__}: {ex}"[:200]
-        res = {"value": world * b / dt, "graphed_ms_per_step": graphed_ms, "grad_allreduce_ms": ar_ms, "grad_mb": (m._flat_grad.numel() * 4 / 1e6 if getattr(m, "_flat_grad", None) is not None else None), "unit": "train samples/s", "ms_per_step": dt * 1e3, "batch_per_gpu": b, "t_size": args.t_size,
+        res = {"value": world * b / dt, "graphed_ms_per_step": graphed_ms, "grad_allreduce_ms": ar_ms, "ms_per_step_no_overlap": no_overlap_ms, "grad_mb": (m._flat_grad.numel() * 4 / 1e6 if getattr(m, "_flat_grad", None) is not None else None), "unit": "train samples/s", "ms_per_step": dt * 1e3, "batch_per_gpu": b, "t_size": args.t_size,
                "steps": steps, "optimizer": "fused AdamW (both groups), clip 1.0, EMA 0.9999", "loss_finite": bool(torch.isfinite(loss)),
                "model_tflops": world * b * 3 * 159.22e9 * args.t_size / 1024.0 / dt / 1e12,
                "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
@@ -411,6 +436,10 @@ def main():
         if args.dtype == "bf16":
             extra["mixed"] = sampler_leg((tstr, "torch.cuda.FloatTensor"), B, T, 200)
             extra["mixed"]["fnet_dtype"] = "f32"
+            # the reference's DEFAULT dtype (configs/audio.yml:26,42 torch.cuda.FloatTensor): what a user who follows INTEGRATION.md A
+            # with the unchanged audio.yml runs -- the exact-fp32 parity kernels (v_mfma_f32_32x32x2_f32), never the headline value
+            extra["f32"] = sampler_leg(("torch.cuda.FloatTensor", None), B, T, 50)
+            extra["f32"]["dtype"] = "f32"
 
     train_leg = None
     if not args.no_train_leg and os.environ.get("DDIMX_BENCH_TRAIN", "1") != "0":
@@ -458,7 +487,7 @@ def main():
                 r["bound"] = "hbm" if r["flops"] / r["alg_bytes"] < ridge else "mfma"
                 r["frac"] = r["gbps"] / HBM_PEAK_GBS if r["bound"] == "hbm" else r["tflops"] / mfma_peak
                 r["frac_hbm"], r["frac_mfma"] = r["gbps"] / HBM_PEAK_GBS, r["tflops"] / mfma_peak
-            dom = max(rows, key=lambda r: r["ms_per_fwd"])
+            dom = max((r for r in rows if not r.get("block")), key=lambda r: r["ms_per_fwd"])
             if dom["bound"] == "hbm":
                 out["roofline"] = {"bound": "hbm", "achieved": dom["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": dom["gbps"] / HBM_PEAK_GBS, "traffic": None}
@@ -481,11 +510,19 @@ def main():
                                         "same kernel runs ~10-15% faster (its input is still in the 256 MB Infinity Cache)")
             # the per-level table the roofline discussion uses: one entry per kernel family and level
             out["roofline"]["per_level"] = [{"kernel": r["kernel"], "level": r["level"], "bound": r["bound"], "frac": round(r["frac"], 4),
-                                             "us": round(r["seconds"] * 1e6, 2)} for r in rows]
+                                             "us": round(r["seconds"] * 1e6, 2)} for r in rows if not r.get("block")]
+            # north_star words its 60 % target on the block path: algorithmic bytes of the whole block / (K1 + K2 + resid) time
+            out["roofline"]["per_block"] = [{"level": r["level"], "us": round(r["seconds"] * 1e6, 2), "gbps": round(r["gbps"], 1),
+                                             "frac_hbm": round(r["frac_hbm"], 4), "frac_mfma": round(r["frac_mfma"], 4)}
+                                            for r in rows if r.get("block")]
+            # a third roof (round 4, profiles/r04/power_probe_convs_sustained.txt): looping this kernel holds the board at its
+            # 1400 W power cap with the shader clock pulled down to 1.9-2.2 GHz -- time per launch = energy per launch / 1400 W
+            out["roofline"]["power_note"] = ("level-0/1 convs run at the board's 1400 W cap (rocm-smi, sustained loop): "
+                                             "neither the HBM nor the MFMA roof is reachable for this op on this board at its energy per launch")
             for r in rows:
                 for k in [k for k in r if k.startswith("seconds")]:
                     r[k.replace("seconds", "us")] = r.pop(k) * 1e6
-            out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+            out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows if not r.get("block")]
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(T, B)
         for k, v in extra.items():

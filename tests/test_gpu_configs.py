@@ -102,8 +102,8 @@ def cfg4_oracle():
 #   bf16 activations + bf16 FNet operands: loss 3.5e-5, element 0.28, norm 7e-5
 # (the worst elements sit in the FNet weight gradients in both bf16 modes: their error comes from the bf16 bottleneck
 #  activations feeding the FNet, not from the GEMM operand type) -> gates at about 2x the measured values
-_CFG4_GATES = {("torch.cuda.FloatTensor", None): (1e-6, 2e-4, 1e-6), ("torch.cuda.BFloat16Tensor", "torch.cuda.FloatTensor"): (1e-4, 0.55, 3e-4),
-               ("torch.cuda.BFloat16Tensor", None): (1e-4, 0.55, 3e-4)}
+_CFG4_GATES = {("torch.cuda.FloatTensor", None): (1e-6, 2e-4, 1e-6), ("torch.cuda.BFloat16Tensor", "torch.cuda.FloatTensor"): (1e-4, 0.40, 3e-4),
+               ("torch.cuda.BFloat16Tensor", None): (1e-4, 0.40, 3e-4)}
 
 
 @pytest.mark.parametrize("key", list(_CFG4_GATES), ids=["f32", "bf16_fnet32", "bf16"])
@@ -645,6 +645,15 @@ def test_staged_grad_sync_runs_on_rccl():
     try:
         ddist.attach_grad_sync(m, bucket_mb=16, overlap=True, min_world=1)
         assert m.grad_sync.active()
+        # the three buckets the staged backward hands over tile the flat gradient buffer exactly: no float is reduced twice or never
+        import ctypes
+        from ddim_audio_amd import _lib
+        lib = _lib.load()
+        rng = (ctypes.c_longlong * 6)()
+        _lib.check(lib.ddimx_grad_buckets(m._handle, rng))
+        spans = sorted((rng[2 * i], rng[2 * i + 1]) for i in range(3))
+        assert spans[0][0] == 0 and spans[-1][1] == int(lib.ddimx_grad_floats(m._handle)) == plain.numel()
+        assert all(lo < hi for lo, hi in spans) and all(spans[i][1] == spans[i + 1][0] for i in range(2))
         for _ in range(2):
             losses.noise_estimation_loss(m, x0, t, e, alphas).backward()
             torch.cuda.synchronize()

@@ -2,7 +2,7 @@
 # A/B of the FNet paths on one box: DDIMX_FNET_DENSE=0 (six launches per layer) vs 1 (fnet_dense.hip), forked and single-stream
 # step, then single-stream kernel averages of both.  usage: tools/fnet_ab.sh OUTDIR
 out=$1; mkdir -p $out
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 B="python bench.py --no-cpu-baseline --no-roofline --no-train-leg --no-extra-legs"
 for round in 1 2; do
   for d in 0 1; do

@@ -4,7 +4,7 @@
 # -- git stash / git worktree, python -m ddim_audio_amd.build -- and copy its libddimx.so to that name; .so files are git-ignored but
 # travel to the GPU box with the snapshot)
 out=$1; mkdir -p $out
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for tag in base new base new; do
   if [ $tag = base ]; then export DDIMX_LIB=$R/ddim_audio_amd/libddimx_base.so; else export DDIMX_LIB=$R/ddim_audio_amd/libddimx.so; fi
   for l in 0 1 2 3 5; do python tools/conv_time.py $l 8 2 >> $out/ops_$tag.txt 2>&1; done

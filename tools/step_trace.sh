@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel timeline of the step (rocprofv3 --kernel-trace, no counters): OUTDIR/kernel_trace_{fork,nofork}.csv
 out=$1; shift
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for kv in "$@"; do export "$kv"; done
 mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
