@@ -154,6 +154,8 @@ struct ddimx_ctx {
     std::vector<FX> fx;
     size_t fx_proj = 0, fx_coutf = 0, fx_coutb = 0;
     bool fx_on = false;
+    const void* frag_packed = nullptr;  // the packed buffer whose fragment-order conv copies (frag_off) are current: written by the
+                                        // eval-only pack (ddimx_pack_fnet_inference), stale after every ddimx_pack_weights
     const void* fx_packed = nullptr;  // the packed buffer whose fnet_dense copies are current (ddimx_pack_fnet_inference), else null
     std::vector<int> emb_off_down, emb_off_up;  // temb chunk offsets per block, execution order
     const unsigned long long* dropout_ctr = nullptr;  // device counter added to every dropout seed (ddimx_set_dropout_counter)
@@ -299,7 +301,9 @@ static int build_plan(ddimx_ctx* c) {
     }
     c->cout_w = add_spec(c, "transformer.compute_out.weight", PK_PERM_ROWS, width, hid);
     c->cout_b = add_spec(c, "transformer.compute_out.bias", PK_PERM_COLS, 1, width);
-    c->fx_on = f.fnet_layers > 0 && hid == 512 && inter % 512 == 0 && width % 512 == 0;  // (row statistics: hid / 16 <= 32 parts)
+    // exactly the shapes fnet_dense_launch instantiates: K = hid = 512 -> N = inter / width ("wide"), and K = inter / width -> N = hid
+    // only as the "deep" form (K >= 4 N: inter, width >= 2048) -- smaller widths take the GEMM path instead of failing in the launcher
+    c->fx_on = f.fnet_layers > 0 && hid == 512 && inter % 512 == 0 && width % 512 == 0 && inter >= 2048 && width >= 2048;
     if (c->fx_on) {
         const size_t wes = c->fnet_bf16 ? 2 : 4;
         auto take = [&](size_t bytes) { const size_t o = c->packed_bytes; c->packed_bytes += al256(bytes); return o; };
@@ -861,7 +865,7 @@ static RBPtrs rb_ptrs(const ddimx_ctx* c, const void* packed, const RBW& r) {
     p.g0 = pf(c, packed, r.g0); p.b0 = pf(c, packed, r.b0); p.g1 = pf(c, packed, r.g1); p.b1 = pf(c, packed, r.b1);
     p.g2 = pf(c, packed, r.g2); p.bias1 = pf(c, packed, r.bias1);
     p.w0 = pv(c, packed, r.w0); p.w1 = pv(c, packed, r.w1);
-    if ((size_t)r.w1 < c->frag_off.size() && c->frag_off[r.w0]) {
+    if (c->frag_packed == packed && (size_t)r.w1 < c->frag_off.size() && c->frag_off[r.w0]) {
         p.w0f = (const char*)packed + c->frag_off[r.w0];
         p.w1f = (const char*)packed + c->frag_off[r.w1];
     }
@@ -1021,6 +1025,7 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
     if (n_params != (int)h->specs.size()) return fail("ddimx_pack_weights: got %d tensors, plan has %zu", n_params, h->specs.size());
     hipStream_t s = (hipStream_t)stream;
     if (h->fx_packed == packed) h->fx_packed = nullptr;  // the folded FNet copies of this buffer are stale from here on
+    if (h->frag_packed == packed) h->frag_packed = nullptr;  // ... and so are the fragment-order conv copies
     const int C5 = h->cfg.ch[h->L - 1], Fr = h->Fr;
     PackCopyBatch batch;  // plain copies (norm weights, biases, dense matrices) go out in batches of kMax per launch
     batch.count = 0;
@@ -1038,18 +1043,10 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
             case PK_COPY: HIPCHK(push_copy(src, (float*)dst, p.numel)); break;
             case PK_CONV:
                 HIPCHK(pack_conv_launch(h->dtype, src, dst, p.d0, p.d1, p.d2, p.d3, s));
-                if ((size_t)i < h->frag_off.size() && h->frag_off[i])
-                    HIPCHK(pack_conv_frag_launch(src, (char*)packed + h->frag_off[i], p.d0, p.d1, p.d2 * p.d3, s));
                 break;
             case PK_CONV_F32: HIPCHK(pack_conv_launch(DT_F32, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
             case PK_CONVT:
                 HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s));
-                if ((size_t)i < h->frag_off.size() && h->frag_off[i]) {  // both row-parity classes, from the sub-pixel form just packed
-                    const size_t cls_bytes = (size_t)6 * 2 * p.d1 * p.d0 * 2;
-                    for (int a = 0; a < 2; ++a)
-                        HIPCHK(pack_frag_from_taps_launch((const char*)dst + a * cls_bytes, (char*)packed + h->frag_off[i] + a * cls_bytes, 6,
-                                                          2 * p.d1, p.d0, s));
-                }
                 break;
             case PK_BIAS2:
                 HIPCHK(push_copy(src, (float*)dst, p.d0));
@@ -1072,6 +1069,22 @@ int ddimx_pack_fnet_inference(ddimx_handle h, void* packed, void* stream) {
     if (!h || !packed) return fail("ddimx_pack_fnet_inference: null argument");
     hipStream_t s = (hipStream_t)stream;
     h->fx_packed = nullptr;
+    h->frag_packed = nullptr;
+    // fragment-order copies of the conv weights (conv_wreg.h / conv_pipe.h: inference walk only -- a training step re-packs after every
+    // optimizer step and never reads them: 79 launches per step), re-ordered from the tap-layout copies just packed
+    for (size_t i = 0; i < h->frag_off.size() && i < h->specs.size(); ++i) {
+        if (!h->frag_off[i]) continue;
+        const ParamSpec& p = h->specs[i];
+        const char* taps = (const char*)packed + p.off;
+        if (p.kind == PK_CONV) {
+            HIPCHK(pack_frag_from_taps_launch(taps, (char*)packed + h->frag_off[i], p.d2 * p.d3, p.d0, p.d1, s));
+        } else if (p.kind == PK_CONVT) {  // both row-parity classes of the sub-pixel form
+            const size_t cls_bytes = (size_t)6 * 2 * p.d1 * p.d0 * 2;
+            for (int a = 0; a < 2; ++a)
+                HIPCHK(pack_frag_from_taps_launch(taps + a * cls_bytes, (char*)packed + h->frag_off[i] + a * cls_bytes, 6, 2 * p.d1, p.d0, s));
+        }
+    }
+    h->frag_packed = packed;
     if (h->fx_on) {
         const ddimx_ctx* c = h;
         const ddimx_config& f = c->cfg;
@@ -1201,7 +1214,7 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
                               pf(c, packed, c->down_b[l]), nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr,
                               at(w.xd[l], act_bytes(l), ln.b0), stats_of(ln, 0), ln.n, H * 2, W * 2};
                 d.groups = true;
-                if ((size_t)c->down_w[l] < c->frag_off.size() && c->frag_off[c->down_w[l]])
+                if (c->frag_packed == packed && (size_t)c->down_w[l] < c->frag_off.size() && c->frag_off[c->down_w[l]])
                     d.wf = (const char*)packed + c->frag_off[c->down_w[l]];
                 return run_conv(d, ln.st, &np, &cs);
             }));
@@ -1256,7 +1269,7 @@ int ddimx_unet_fwd_forked(ddimx_handle h, const void* packed, const ddimx_tables
                               nullptr, 0, nullptr, nullptr, XF_NONE, 0, at(w.xd[l - 1], act_bytes(l - 1), ln.b0),
                               at(w.xu[l - 1], act_bytes(l - 1), ln.b0), stats_of(ln, 0), ln.n, H, W};
                 u.groups = true;
-                if ((size_t)c->up_w[l] < c->frag_off.size() && c->frag_off[c->up_w[l]])
+                if (c->frag_packed == packed && (size_t)c->up_w[l] < c->frag_off.size() && c->frag_off[c->up_w[l]])
                     u.wf = (const char*)packed + c->frag_off[c->up_w[l]];
                 return run_conv(u, ln.st, &np, &cs);
             }));

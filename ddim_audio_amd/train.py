@@ -225,7 +225,13 @@ class GraphedTrainStep:
         self.graph = g
         # what the graph points at, kept next to it: the flat gradient buffer and the training workspace are re-used by eager
         # steps, but must not be FREED (a batch-shape change re-allocates them) while this graph can still be replayed
+        # ... and so are the posenc / DFT tables (Model._tables keeps only the latest T: an eval forward at another length would free
+        # them), the eval workspaces and the embedding table (Model.captured_refs).  The model's buffer generation is recorded: a
+        # replay after .to() / .type() / a re-allocation would run on pointers of an earlier generation
         self._refs = [getattr(self.model, n, None) for n in ("_flat_grad", "_train_ws", "_packed", "_packed_bwd")]
+        if hasattr(self.model, "captured_refs"):
+            self._refs += self.model.captured_refs()
+        self._gen = getattr(self.model, "_gen", None)
 
     def close(self):
         """Back to eager stepping.  The graph goes first, then the buffers it points at."""
@@ -263,6 +269,10 @@ class GraphedTrainStep:
                     self.model._alias_leaves = False
             cur.wait_stream(self._side)
             return out
+        if self.graph is not None and getattr(self.model, "_gen", None) != self._gen:
+            # the model re-allocated a buffer the graph points at (another T through an eval forward, .to() / .type(), a repack into
+            # a new buffer): drop the graph (its buffers stay alive in _refs until it is gone) and capture again on this call
+            self.close()
         if self.graph is None:
             self._capture(x)
         if x.shape != self.x.shape:

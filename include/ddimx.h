@@ -94,11 +94,14 @@ long long ddimx_workspace_bytes(ddimx_handle h, int B, int T);
  * in NHWC token order).  Must be re-run whenever parameters change (optimizer step, load_state_dict,
  * EMAHelper.ema: models/ema.py:25-30). */
 int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, void* packed, void* stream);
-/* Inference-only second copies of the FNet weights for the launch-lean bottleneck path (csrc/fnet_dense.hip: MFMA fragment order,
- * the LayerNorms' gamma / beta folded into the next matrix, one hidden-DFT table per layer; models/diffusion.py:131-167,
- * modeling_fnet.py:138-279), derived from what ddimx_pack_weights wrote into `packed`; call it after ddimx_pack_weights when the
- * weights are packed for eval mode.  Without it (or after a later ddimx_pack_weights into the same buffer) the forward takes the
- * GEMM path: same results within rounding, 77 launches instead of 39. */
+/* Inference-only second copies, derived from what ddimx_pack_weights wrote into `packed`; call it after ddimx_pack_weights when the
+ * weights are packed for eval mode (a training step re-packs after every optimizer step and reads none of them):
+ * - the conv weights of Residual_Block / Downsample / Upsample in MFMA fragment order (csrc/conv_wreg.h, conv_pipe.h;
+ *   models/diffusion.py:28-40,59-78) -- without them the convolutions run through conv_mfma_kernel's LDS weight path;
+ * - the FNet weights for the launch-lean bottleneck path (csrc/fnet_dense.hip: fragment order, the LayerNorms' gamma / beta folded
+ *   into the next matrix, one hidden-DFT table per layer; models/diffusion.py:131-167, modeling_fnet.py:138-279) -- without them
+ *   the forward takes the GEMM path: 77 launches instead of 39.
+ * Same results within rounding either way; a later ddimx_pack_weights into the same buffer invalidates both. */
 int ddimx_pack_fnet_inference(ddimx_handle h, void* packed, void* stream);
 
 /* Model.forward (models/diffusion.py:237-294), eval mode: x [B][C][T][F] fp32, t [B] int64 -> eps. */

@@ -777,3 +777,53 @@ def test_graphed_train_step_with_device_resident_inputs_and_no_host_reads():
     torch.cuda.synchronize()
     for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(a, b), k
+
+
+def test_graphed_train_step_keeps_its_tables_and_recaptures_when_the_model_reallocates():
+    """the train graph points at the posenc / DFT tables too, and ``Model._tables`` keeps only the latest T -- an eval
+    forward at another length between replays used to free tables the graph still read.  Now the graph's owner keeps
+    ``Model.captured_refs()`` next to the graph, records ``Model._gen`` at capture and captures again when it moved: six graphed
+    steps with an eval forward at another T in the middle must leave exactly the state of six eager steps (and two captures)."""
+    from ddim_audio_amd import train
+    cfg = configs.tiny_config("torch.cuda.FloatTensor")
+    cfg.optimization.optimizer.default.optimizer = "AdamW"
+    alphas = make_schedule(cfg.diffusion)[1].cuda()
+    n = 6
+    xs = [synth.gaussian(f"regen.x{i}", (4, cfg.model.channels, 32, cfg.model.f_size)).cuda() for i in range(n)]
+    es = [synth.gaussian(f"regen.e{i}", (4, cfg.model.channels, 32, cfg.model.f_size)).cuda() for i in range(n)]
+    ts = [torch.tensor([7 + i, 992 - i, 300 + i, 699 - i], device="cuda") for i in range(n)]
+    other = synth.gaussian("regen.other", (2, cfg.model.channels, 64, cfg.model.f_size)).cuda()
+
+    def make():
+        torch.manual_seed(11)
+        m = synth.fill_module(D.Model(cfg), 5)
+        return m, train.TrainingState(cfg, m)
+
+    def disturb(m):
+        m.eval()
+        with torch.no_grad():
+            m(other, torch.tensor([3, 500], device="cuda"))   # another T: new tables, new workspace -> the generation moves
+        junk = [torch.full((1 << 18,), float("nan"), device="cuda") for _ in range(8)]  # would land in freed blocks
+        del junk
+        m.train()
+
+    m1, s1 = make()
+    for i in range(n):
+        if i == 4:
+            disturb(m1)
+        train.train_step(m1, xs[i], s1, alphas, e=es[i], t=ts[i])
+    m2, s2 = make()
+    step = train.GraphedTrainStep(m2, s2, alphas, warmup=1)
+    captures = 0
+    for i in range(n):
+        if i == 4:
+            assert step.graph is not None
+            disturb(m2)
+        had = step.graph is not None
+        step(xs[i], e=es[i], t=ts[i])
+        captures += int(step.graph is not None and (not had or i == 4))
+    torch.cuda.synchronize()
+    assert captures == 2, captures
+    step.close()
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k
