@@ -199,6 +199,10 @@ class GraphedTrainStep:
         self.t = torch.zeros(x.size(0), dtype=torch.int64, device=dev)
         self.alphas = self.alphas.to(dev)
         snap = self._snapshot()
+        if hasattr(self.model, "_ensure_tables"):
+            # host-built tables (posenc, DFT) must exist before the capture: building them is a host-to-device copy.  (Nothing else is
+            # prepared here: the weight re-pack must stay INSIDE the captured forward, every replay follows an optimizer step.)
+            self.model._ensure_tables(x.size(2), dev)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         # The device-scalar hooks exist only while the capture runs: the optimizers read (lr, bias corrections) from _d_dyn and
