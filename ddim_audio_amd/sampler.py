@@ -39,7 +39,7 @@ class DDIMStepper:
     side stream or inside the capture: the workspace is reserved and the eps buffer allocated on the launch stream before.
     """
 
-    def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None):
+    def __init__(self, model, xt, coef64, use_graph=True, noise_fn=None, slot=0, fork=True):
         self.graph = None          # first attribute: close() / __del__ must find it whatever else failed
         self._ctx = self._refs = None
         self.lib = _lib.load()
@@ -58,6 +58,9 @@ class DDIMStepper:
         self._capture_pending = self.use_graph
         self._gen = None
         self.native = hasattr(model, "forward_slot")  # ddim_audio_amd.Model; anything else is called as model(x, t)
+        # workspace slot of the model this stepper computes in (steppers that run concurrently on different streams must not share
+        # scratch memory) and whether its forward may fork into two batch shards itself
+        self.slot, self.fork = slot, fork
         self.eps = torch.empty_like(xt) if self.native else None  # the forward writes here: no allocation per step
 
     def _prepare(self):
@@ -65,14 +68,14 @@ class DDIMStepper:
         if self.native:
             dev, t_len = self.xt.device, self.xt.size(2)
             self.model.prepare(dev, t_len)
-            self.model.reserve(dev, self.xt.size(0), t_len, 0)
+            self.model.reserve(dev, self.xt.size(0), t_len, self.slot)
 
     def _launch(self, noise):
         lib, st = self.lib, _lib.stream()
         xt, t, x0 = self.xt, self.t, self.x0
         _lib.check(lib.ddimx_step_begin(_lib.ptr(self.coef), _lib.ptr(self.counter), _lib.ptr(t), t.numel(), st))
         if self.native:
-            et = self.model(xt, t, _ctx=self._ctx, _out=self.eps)
+            et = self.model(xt, t, _slot=self.slot, _fork=self.fork, _ctx=self._ctx, _out=self.eps)
         else:
             et = self.model(xt, t)
             if et.dtype != torch.float32 or not et.is_contiguous():
@@ -121,7 +124,7 @@ class DDIMStepper:
 
     def _capture(self):
         dev = self.xt.device
-        if self.native and self.model.fork_mask and self.xt.size(0) >= 4:
+        if self.native and self.fork and self.model.fork_mask and self.xt.size(0) >= 4:
             self._ctx = self.model.new_fork_context(dev)  # created (and first recorded) eagerly, owned here
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
