@@ -58,6 +58,7 @@ _SIGS = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, POINTER(c_void_p), c_int,
                                       c_void_p]),
     "ddimx_sqerr_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
+    "ddimx_sqerr_loss_bwd_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     "ddimx_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_from_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ddimx_pack_conv": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -1909,6 +1909,10 @@ int ddimx_sqerr_loss_bwd(const float* e, const float* out, const float* g_per_sa
     HIPCHK(sqerr_bwd_launch(e, out, g_per_sample, d_out, B, per_sample, (hipStream_t)stream));
     return 0;
 }
+int ddimx_sqerr_loss_bwd_mean(const float* e, const float* out, const float* g, float* d_out, int B, long long per_sample, void* stream) {
+    HIPCHK(sqerr_bwd_launch(e, out, g, d_out, B, per_sample, (hipStream_t)stream, 1));
+    return 0;
+}
 
 // ---- per-op entry points ---------------------------------------------------------------------------
 int ddimx_to_nhwc(int dtype, const float* nchw, void* nhwc, int B, int C, int H, int W, void* stream) {

@@ -60,6 +60,6 @@ size_t edge_wgrad_partial_floats(int dtype, int B, int C, int NI, int H, int W);
 hipError_t edge_wgrad_launch(int dtype, int mode, const void* g1, const void* g2, const float* S, float* partial, float* dW,
                              float* db, int B, int C, int NI, int H, int W, hipStream_t s);
 // d_out[b] = 2 g[b] (out[b] - e[b]); g: upstream gradient of the per-sample losses [B]
-hipError_t sqerr_bwd_launch(const float* e, const float* out, const float* g, float* d, int B, long long per, hipStream_t s);
+hipError_t sqerr_bwd_launch(const float* e, const float* out, const float* g, float* d, int B, long long per, hipStream_t s, int with_mean = 0);
 
 }  // namespace ddimx

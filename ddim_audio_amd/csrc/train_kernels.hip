@@ -1129,16 +1129,17 @@ hipError_t edge_wgrad_launch(int dtype, int mode, const void* g1, const void* g2
 }
 
 // d(out)[b] = 2 * g[b] * (out[b] - e[b])   (functions/losses.py:18: per-sample sum of squares; g = upstream gradient per sample)
+// with_mean: g has B + 1 entries, the last one the upstream gradient of the batch MEAN (the loss vector's [B] entry): + g[B] / B per sample
 __global__ void __launch_bounds__(256) sqerr_bwd_kernel(const float* __restrict__ e, const float* __restrict__ o,
-                                                        const float* __restrict__ g, float* __restrict__ d, long long per) {
+                                                        const float* __restrict__ g, float* __restrict__ d, long long per, int with_mean) {
     const int b = blockIdx.y;
-    const float c = 2.0f * g[b];
+    const float c = 2.0f * (g[b] + (with_mean ? g[gridDim.y] / (float)gridDim.y : 0.f));
     const size_t base = (size_t)b * per;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < per; i += gridDim.x * 256ll) d[base + i] = c * (o[base + i] - e[base + i]);
 }
-hipError_t sqerr_bwd_launch(const float* e, const float* out, const float* g, float* d, int B, long long per, hipStream_t s) {
+hipError_t sqerr_bwd_launch(const float* e, const float* out, const float* g, float* d, int B, long long per, hipStream_t s, int with_mean) {
     const int blocks = (int)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024);
-    hipLaunchKernelGGL(sqerr_bwd_kernel, dim3(blocks, B), dim3(256), 0, s, e, out, g, d, per);
+    hipLaunchKernelGGL(sqerr_bwd_kernel, dim3(blocks, B), dim3(256), 0, s, e, out, g, d, per, with_mean);
     return hipGetLastError();
 }
 

@@ -29,11 +29,11 @@ class _SqErrFn(torch.autograd.Function):
         out, e = ctx.saved_tensors
         b = out.size(0)
         per = out.numel() // b
-        # the [B] entry is the batch mean (functions/losses.py:18): fold its upstream gradient into the per-sample ones
-        gp = (g[:b] + g[b] / b).contiguous()
+        # the [B] entry is the batch mean (functions/losses.py:18): the kernel folds its upstream gradient into the per-sample ones
+        gc = g.contiguous()  # (what autograd hands over already is: no launch)
         d = torch.empty_like(out)
         with torch.cuda.device(out.device):
-            _lib.check(lib.ddimx_sqerr_loss_bwd(_lib.ptr(e), _lib.ptr(out), _lib.ptr(gp), _lib.ptr(d), b, per, _lib.stream()))
+            _lib.check(lib.ddimx_sqerr_loss_bwd_mean(_lib.ptr(e), _lib.ptr(out), _lib.ptr(gc), _lib.ptr(d), b, per, _lib.stream()))
         return d, None
 
 

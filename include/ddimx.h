@@ -161,6 +161,9 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
 /* backward of the per-sample squared-error loss (functions/losses.py:18): d_out[b] = 2 g[b] (out[b] - e[b]) */
 int ddimx_sqerr_loss_bwd(const float* e, const float* out, const float* g_per_sample, float* d_out, int B,
                          long long per_sample, void* stream);
+/* the same against the gradient of ddimx_sqerr_loss's whole [B + 1] vector (per-sample losses, then their batch mean --
+ * functions/losses.py:16-18 keepdim / mean): d_out[b] = 2 (g[b] + g[B] / B) (out[b] - e[b]) */
+int ddimx_sqerr_loss_bwd_mean(const float* e, const float* out, const float* g, float* d_out, int B, long long per_sample, void* stream);
 
 /* ---- per-op entry points (same kernels as ddimx_unet_fwd; used by the parity tests) ------------- */
 /* layout helpers: NCHW fp32 <-> NHWC activation dtype */
