@@ -63,7 +63,10 @@ struct PipeCfg {
     static constexpr int GN_BYTES = NWAVES * kGroups * 2 * 4;
     static constexpr int OFF_TR = 2 * HALO_BYTES, OFF_DUMP = OFF_TR + NWAVES * TR_BYTES, OFF_GN = OFF_DUMP + DUMP_BYTES;
     static constexpr int LDS_BYTES = OFF_GN + GN_BYTES + 256;
-    static constexpr int PD = 2, NBQ = 3;                // B operands are read PD steps ahead into a ring of NBQ
+#ifndef DDIMX_PIPE_PD
+#define DDIMX_PIPE_PD 2
+#endif
+    static constexpr int PD = DDIMX_PIPE_PD, NBQ = PD + 1;   // B operands are read PD steps ahead into a ring of NBQ
     // Work units of the two filler stages.  A wave issues one instruction per ~4.75 cycles of any kind (transcendentals 8.3); five
     // scalar vector instructions hide in the wave's own MFMA (32.6 cycles), an MFMA costs the stream ~9 (tools/dbg/mfma_valu_overlap.hip,
     // profiles/r04/mfma_valu_overlap_microbench.txt).  A transcendental result needs one independent instruction before its consumer
@@ -331,6 +334,11 @@ __global__ void __launch_bounds__(F::NTHREADS, F::MINW) conv3_pipe_kernel(const 
     // ---- the tile body -------------------------------------------------------------------------------------------------------------------
     auto body = [&](auto xfn_, int cur, int t) __attribute__((always_inline)) {
         constexpr bool XFN = decltype(xfn_)::value;  // a next tile exists: stage XF runs
+        // the two copies of the body share the previous block's epilogue arithmetic: left alone, LLVM hoists it (16 v_mul + 16 v_exp) in
+        // front of the branch that picks the copy -- out of the MFMA gaps it was scheduled into.  An empty asm that "redefines" the
+        // accumulator, with a different text per copy, keeps each copy's arithmetic where it was written.
+        if constexpr (XFN) asm volatile("; tile body, a next tile exists" : "+v"(acc1));
+        else asm volatile("; tile body, last tile of the workgroup" : "+v"(acc1));
         const char* const hsrc = halo + cur * F::HALO_BYTES + lanebase;
         char* const hdst = halo + (cur ^ 1) * F::HALO_BYTES;
         const bool has2 = t + 2 < t_end;
