@@ -57,6 +57,10 @@ _SIGS = {
     "ddimx_unet_bwd_staged": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, POINTER(c_void_p), c_int,
                                       c_void_p]),
+    "ddimx_bwd_side_events": (c_int, [c_void_p]),
+    "ddimx_unet_bwd_forked": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(DdimxTables), c_void_p, c_longlong, c_void_p, c_longlong,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_ulonglong, POINTER(c_void_p), c_int,
+                                      c_void_p, c_void_p, POINTER(c_void_p), c_int]),
     "ddimx_sqerr_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     "ddimx_sqerr_loss_bwd_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     "ddimx_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -21,12 +22,17 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int fnet_dense, conv_pipe, pipe_tpw, bwd_stats_fused, gn_dbg, conv_wreg, conv_wps, conv_var, wgrad_split;
+    int fnet_dense, conv_pipe, pipe_tpw, bwd_stats_fused, gn_dbg, conv_wreg, conv_wps, conv_var, wgrad_split, wgrad_side, wgrad_hold, wgrad_flush;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);     // tools/conv_tune.py: force a candidate tile variant of conv_mfma_kernel
         conv_wps = geti("DDIMX_CONV_WPS", 0);      // tools/conv_tune.py: workgroups per sample
         wgrad_split = geti("DDIMX_WGRAD_SPLIT", 0);  // tools/wgrad_one.py
+        wgrad_side = geti("DDIMX_WGRAD_SIDE", 1);    // tools/wgside_trace.sh A/B: 0 = the weight gradients stay on the backward's stream, 2 = forked early
+        // ... and the up path's weight gradients of levels < wgrad_hold wait (in `du` buffers of their own) for the bottleneck's
+        // backward, whose launch-bound FNet kernels leave the chip idle (WgSide::held)
+        wgrad_hold = geti("DDIMX_WGRAD_HOLD", 2);
+        wgrad_flush = geti("DDIMX_WGRAD_FLUSH", 99);  // A/B: issue the held ones when the up path's backward enters this level (default: at the FNet)
         bwd_stats_fused = geti("DDIMX_BWD_STATS_FUSED", 1);  // A/B: 0 = GroupNorm-backward statistics by their own pass
         gn_dbg = geti("DDIMX_GN_DBG", 0);          // tools/gn_dbg.sh: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
         fnet_dense = geti("DDIMX_FNET_DENSE", 1);  // tools/fnet_ab.sh: 0 = the GEMM path for the FNet at S <= 32
@@ -772,6 +778,75 @@ static int run_wgrad(int dtype, int mode, int ci, int co, const void* a_t, const
     return 0;
 }
 
+// The weight-gradient branch of the backward (ddimx_unet_bwd_forked).  A conv's weight gradient needs its output gradient `du`
+// and the saved forward tensor and feeds nothing but the parameter's gradient slot, so it leaves the data-gradient chain: it is
+// issued on a second stream behind an event and the chain goes on.  WHEN it is issued decides what it shares the chip with, and
+// that decides whether anything is gained (profiles/r04/wgside/): next to the data-gradient convs (forked as soon as `du`
+// exists) both kernels want the same VALU + matrix cycles and each simply takes longer (wgrad 128 -> 204 us, conv 137 -> 196 us
+// on average: zero sum); next to the GroupNorm-backward passes (HBM only) the two overlap for real.  So both weight gradients of a
+// block are forked behind its LAST data-gradient conv and run beside the block's final apply pass and the next block's statistics
+// and first apply pass.  The branch owns its slab buffer and four `du` buffers: a block writes du2 / du1 into the pair of its
+// parity, and before the block after next overwrites that pair it waits for the event behind the pair's last reader.  Every fork,
+// release and join records an event of its own (nothing is re-recorded inside one capture).
+struct WgSide {
+    hipStream_t st = nullptr;  // null: one stream, nothing below is used
+    void* const* ev = nullptr;
+    int n = 0, used = 0;
+    int early = 0;             // DDIMX_WGRAD_SIDE=2 (A/B): fork each weight gradient as soon as its `du` exists
+    float* partial = nullptr;
+    void* du[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t du_free[2] = {nullptr, nullptr};
+    int blk = 0;               // Residual_Blocks seen so far (parity -> buffer pair)
+    // Weight gradients that wait for the bottleneck: the up path's blocks of the largest levels write their du2 / du1 into buffers
+    // of their own (`hold`, non-null for such a block) and queue their launches here; the queue is issued on the branch when the
+    // chain enters the FNet backward -- ~3.5 ms of launch-bound kernels at 32 samples, under which these run almost for free.
+    void* const* hold = nullptr;
+    std::vector<std::function<int()>> held;
+    bool on() const { return st != nullptr; }
+    int flush_held(hipStream_t s) {
+        if (held.empty()) return 0;
+        CHK(fork(s));
+        for (auto& f : held) CHK(f());
+        held.clear();
+        return 0;
+    }
+    int next(hipEvent_t* e) {
+        if (used >= n) return fail("ddimx_unet_bwd_forked: %d events are not enough (ddimx_bwd_side_events)", n);
+        *e = (hipEvent_t)ev[used++];
+        return 0;
+    }
+    // the branch may read what `s` has produced so far
+    int fork(hipStream_t s) {
+        hipEvent_t e;
+        CHK(next(&e));
+        HIPCHK(hipEventRecord(e, s));
+        HIPCHK(hipStreamWaitEvent(st, e, 0));
+        return 0;
+    }
+    // everything the branch has been given so far reads buffer pair p no more
+    int release(int p) {
+        hipEvent_t e;
+        CHK(next(&e));
+        HIPCHK(hipEventRecord(e, st));
+        du_free[p] = e;
+        return 0;
+    }
+    // `s` is about to overwrite buffer pair p
+    int claim(int p, hipStream_t s) {
+        if (du_free[p]) HIPCHK(hipStreamWaitEvent(s, du_free[p], 0));
+        du_free[p] = nullptr;
+        return 0;
+    }
+    int join(hipStream_t s) {
+        hipEvent_t e;
+        CHK(next(&e));
+        HIPCHK(hipEventRecord(e, st));
+        HIPCHK(hipStreamWaitEvent(s, e, 0));
+        du_free[0] = du_free[1] = nullptr;
+        return 0;
+    }
+};
+
 // Gradient destinations of one Residual_Block (fp32, the parameters' own layouts); dtemb: [B][stride] slice.
 struct RBGrads {
     float *g0, *b0, *g1, *b1, *g2, *w0, *w1, *bias1;
@@ -799,10 +874,23 @@ static size_t rb_bwd_stats_floats(int dtype, int B, int HW, int C) { return (siz
 // gradients are WRITTEN (not accumulated).  wd0 / wd1: data-gradient packings of conv.0 / conv.1.
 static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, const void* dy, const void* extra, void* dx,
                             const float* gam0, const float* gam1, const float* gam2, const void* wd0, const void* wd1,
-                            const RBGrads& gr, const RBBwdWs& w, int B, int H, int W, hipStream_t s) {
+                            const RBGrads& gr, const RBBwdWs& w, int B, int H, int W, hipStream_t s, WgSide* sd = nullptr) {
     const int HW = H * W;
     const double cnt = (double)HW * (C / kGroups);
     const int np = resid_nparts(dtype, HW, C);
+    const bool side = sd && sd->on();
+    void* const* hold = side ? sd->hold : nullptr;         // this block's weight gradients wait for the bottleneck
+    const int par = side && !hold ? (sd->blk++ & 1) : 0;
+    void* const du2 = hold ? hold[0] : (side ? sd->du[2 * par] : w.du);      // gradient of conv.1's output / of conv.0's output
+    void* const du1 = hold ? hold[1] : (side ? sd->du[2 * par + 1] : w.du);
+    hipStream_t const sw = side ? sd->st : s;              // the weight gradients' stream
+    float* const wpart = side ? sd->partial : w.partial;
+    const bool early = side && sd->early && !hold;
+    const void* const u1 = tp.u1;
+    const float *const sc1 = tp.sc(1, B, C), *const sh1 = tp.sh(1, B, C), *const sc0 = tp.sc(0, B, C), *const sh0 = tp.sh(0, B, C);
+    float *const gw1 = gr.w1, *const gw0 = gr.w0;
+    auto wgrad1 = [=]() { return run_wgrad(dtype, CONV3, C, C, u1, du2, sc1, sh1, XF_SILU_AFFINE, wpart, gw1, B, H, W, sw); };
+    auto wgrad0 = [=]() { return run_wgrad(dtype, CONV3, C, C, x, du1, sc0, sh0, XF_AFFINE_SILU, wpart, gw0, B, H, W, sw); };
     float* const slot0 = w.slots ? w.slots : w.dgb;  // [B][2][C] each; with deferral every use keeps its own slot
     const size_t slot_f = (size_t)B * 2 * C;
     float* const dgb2 = slot0;
@@ -813,11 +901,13 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     HIPCHK(gn_bwd_stats_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.stats, B, HW, C, s));
     HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam2, tp.mr(2, B, C), w.coef, dgb2, B, s));
     CHK(push_colsum(w, dgb2, B, 2 * C, C, gr.g2, s));
-    HIPCHK(gn_bwd_apply_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.coef, nullptr, nullptr, w.du, w.sums, B, HW, C, s));
+    if (side && !hold) CHK(sd->claim(par, s));
+    HIPCHK(gn_bwd_apply_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.coef, nullptr, nullptr, du2, w.sums, B, HW, C, s));
     HIPCHK(partsum_launch(w.sums, B, np, C, sumb, C, s));           // per-sample channel sums of du2
     CHK(push_colsum(w, sumb, B, C, C, gr.bias1, s));                // conv.1.bias
     // ---- conv.1: weight gradient against GN1(SiLU(u1)), data gradient -> dg
-    CHK(run_wgrad(dtype, CONV3, C, C, tp.u1, w.du, tp.sc(1, B, C), tp.sh(1, B, C), XF_SILU_AFFINE, w.partial, gr.w1, B, H, W, s));
+    if (early) CHK(sd->fork(s));
+    if (!side || early) CHK(wgrad1());
     // The data-gradient convs take the GroupNorm-backward partial sums of their own output in their epilogue (ConvCfg::BWD:
     // one more read of u1 / x there instead of a pass over dg and u1 / x); the slab count is then the conv's, not resid's.
     auto fused_stats = [&](ConvCall& d, const void* aux, const float* asc, const float* ash, int mode, int* nparts) -> int {
@@ -828,7 +918,7 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
         d.aux = aux; d.aux_scale = asc; d.aux_shift = ash; d.bwd_mode = mode; d.stats = w.stats;
         return 0;
     };
-    ConvCall d1 = {dtype, CONV3, C, C, w.du, wd1, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
+    ConvCall d1 = {dtype, CONV3, C, C, du2, wd1, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
     int np1 = 0;
     CHK(fused_stats(d1, tp.u1, nullptr, nullptr, 1, &np1));
     CHK(run_conv(d1, s, nullptr, nullptr));
@@ -837,14 +927,24 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     HIPCHK(gn_bwd_finalize_launch(w.stats, np1, C, cnt, gam1, tp.mr(1, B, C), w.coef, dgb1, B, s));
     CHK(push_colsum(w, dgb1, B, 2 * C, C, gr.g1, s));
     CHK(push_colsum(w, dgb1 + C, B, 2 * C, C, gr.b1, s));
-    HIPCHK(gn_bwd_apply_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.coef, nullptr, nullptr, w.du, w.sums, B, HW, C, s));
+    HIPCHK(gn_bwd_apply_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.coef, nullptr, nullptr, du1, w.sums, B, HW, C, s));
     if (gr.dtemb) HIPCHK(partsum_launch(w.sums, B, np, C, gr.dtemb, gr.dtemb_stride, s));  // timestep-embedding chunk
     // ---- conv.0: weight gradient against SiLU(GN0(x)), data gradient -> dg
-    CHK(run_wgrad(dtype, CONV3, C, C, x, w.du, tp.sc(0, B, C), tp.sh(0, B, C), XF_AFFINE_SILU, w.partial, gr.w0, B, H, W, s));
-    ConvCall d0 = {dtype, CONV3, C, C, w.du, wd0, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
+    if (early) CHK(sd->fork(s));
+    if (!side || early) CHK(wgrad0());
+    ConvCall d0 = {dtype, CONV3, C, C, du1, wd0, nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr, w.dg, nullptr, B, H, W};
     int np0 = 0;
     CHK(fused_stats(d0, x, tp.sc(0, B, C), tp.sh(0, B, C), 2, &np0));
     CHK(run_conv(d0, s, nullptr, nullptr));
+    if (hold) {
+        sd->held.push_back(wgrad1);
+        sd->held.push_back(wgrad0);
+    } else if (side && !early) {  // both weight gradients behind the last data-gradient conv: beside the HBM-bound passes that follow
+        CHK(sd->fork(s));
+        CHK(wgrad1());
+        CHK(wgrad0());
+    }
+    if (side && !hold) CHK(sd->release(par));
     // ---- SiLU behind GN0, GN0 itself, and the identity path
     if (!np0) { HIPCHK(gn_bwd_stats_launch(dtype, 1, w.dg, x, tp.sc(0, B, C), tp.sh(0, B, C), w.stats, B, HW, C, s)); np0 = np; }
     HIPCHK(gn_bwd_finalize_launch(w.stats, np0, C, cnt, gam0, tp.mr(0, B, C), w.coef, dgb0, B, s));
@@ -1385,8 +1485,9 @@ struct TrainWs {
     float *stats, *scale, *shift;
     float *Ut, *Hb, *O, *gpart;
     std::vector<void*> Ga, Gb, GS;
-    void *gA, *du, *dg;
-    float *coef, *dgb, *sums, *partial, *slots;
+    void *gA, *du, *dg, *du_b[3];          // du_b / partial_b: the weight-gradient branch's further `du` buffers and its own slabs (WgSide)
+    float *coef, *dgb, *sums, *partial, *partial_b, *slots;
+    std::vector<std::vector<void*>> hold;  // [level][2 r + {du2, du1}]: the up path's held weight gradients (WgSide::held)
     float *dtemb, *dh2, *dh1;
     float *dO, *dXa, *dXb, *dZ, *dH, *T1, *T2, *lnpart, *dTok, *pgrad;
     size_t total;
@@ -1428,6 +1529,10 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
     w->gA = cv.take((size_t)B * T * f.f_size * f.ch[0] * es);
     w->du = cv.take(hmax);
     w->dg = cv.take(hmax);
+    for (int i = 0; i < 3; ++i) w->du_b[i] = cv.take(hmax);
+    w->hold.assign(L, {});
+    for (int l = 0; l < L - 1 && l < knobs().wgrad_hold; ++l)
+        for (int i = 0; i < 2 * f.res[l]; ++i) w->hold[l].push_back(cv.take((size_t)B * (T >> l) * (f.f_size >> l) * f.ch[l] * es));
     w->stats = (float*)cv.take(stats_f * 4);
     w->scale = (float*)cv.take((size_t)B * cmax * 4);
     w->shift = (float*)cv.take((size_t)B * cmax * 4);
@@ -1436,6 +1541,7 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
     w->slots = (float*)cv.take((size_t)kDeferBlocks * 4 * B * 2 * cmax * 4);
     w->sums = (float*)cv.take(sums_f * 4);
     w->partial = (float*)cv.take(part_f * 4);
+    w->partial_b = (float*)cv.take(part_f * 4);
     w->dtemb = (float*)cv.take((size_t)B * c->E * 4);
     w->dh2 = (float*)cv.take((size_t)B * 512 * 4);
     w->dh1 = (float*)cv.take((size_t)B * 512 * 4);
@@ -1772,9 +1878,33 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
                           long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
                           const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed,
                           void* const* bucket_events, int n_events, void* stream) {
+    return ddimx_unet_bwd_forked(h, packed, packed_bwd, tables, workspace, workspace_bytes, tape, tape_bytes, x, t, d_eps, grads, B, T,
+                                 dropout_p, seed, bucket_events, n_events, stream, nullptr, nullptr, 0);
+}
+
+// Events ddimx_unet_bwd_forked needs for its weight-gradient branch: per Residual_Block two forks and two buffer releases, one fork
+// per Downsample / Upsample weight and for the output conv's, the fork in front of bucket 0's event, the final join.
+int ddimx_bwd_side_events(ddimx_handle h) {
+    if (!h) return 0;
+    int blocks = 0;
+    for (int l = 0; l < h->L; ++l) blocks += 2 * h->cfg.res[l];
+    return 4 * blocks + 2 * (h->L - 1) + 3;
+}
+
+// The backward with its weight gradients on `side_stream` (WgSide above; results are bit-identical to the one-stream call: same
+// kernels, same partitions, same order of additions).  The branch is joined into `stream` before the call returns; bucket 0's event
+// is recorded on the side stream (behind the up path's last weight gradient AND the chain's batch sums), the other two on `stream`.
+// side_stream null (or DDIMX_WGRAD_SIDE=0): one stream.
+int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                          long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
+                          const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed,
+                          void* const* bucket_events, int n_events, void* stream, void* side_stream, void* const* side_events,
+                          int n_side_events) {
     if (!h || !packed || !packed_bwd || !tables || !workspace || !tape || !x || !t || !d_eps || !grads)
         return fail("ddimx_unet_bwd: null argument");
     if (n_events != 0 && (n_events != 3 || !bucket_events)) return fail("ddimx_unet_bwd_staged: pass 0 or 3 bucket events");
+    if (side_stream && (!side_events || n_side_events < ddimx_bwd_side_events(h)))
+        return fail("ddimx_unet_bwd_forked: %d side events, the plan needs %d", n_side_events, ddimx_bwd_side_events(h));
     const ddimx_ctx* c = h;
     const ddimx_config& f = c->cfg;
     const int L = c->L, dt = c->dtype;
@@ -1799,6 +1929,14 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
     }
     auto G = [&](int i) { return grads + goff[i]; };
     RBBwdWs rw = {w.du, w.dg, w.stats, w.coef, w.dgb, w.sums, w.partial};
+    WgSide sd;
+    if (side_stream && side_stream != stream && knobs().wgrad_side != 0) {
+        sd.st = (hipStream_t)side_stream; sd.ev = side_events; sd.n = n_side_events;
+        sd.early = knobs().wgrad_side == 2;
+        sd.partial = w.partial_b; sd.du[0] = w.du; sd.du[1] = w.du_b[0]; sd.du[2] = w.du_b[1]; sd.du[3] = w.du_b[2];
+    }
+    hipStream_t const sw = sd.on() ? sd.st : s;            // the weight gradients' stream ...
+    float* const wpart = sd.on() ? sd.partial : w.partial;  // ... and slab buffer
     ColsumBatch defer;
     defer.count = 0;
     rw.defer = &defer;
@@ -1822,28 +1960,33 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
 
     // ---- output conv (models/diffusion.py:283-292): gradient of `x + hidden[0]`, weight / bias gradients
     HIPCHK(conv_out_bwd_data_launch(dt, d_eps, pf(c, packed, c->out_w), w.gA, B, f.ch[0], f.in_channels, T, f.f_size, s));
-    HIPCHK(edge_wgrad_launch(dt, 1, tp.up_y[0].back(), tp.A, d_eps, w.partial, G(c->out_w), G(c->out_b), B, f.ch[0], f.in_channels, T,
-                             f.f_size, s));
+    if (sd.on()) CHK(sd.fork(s));
+    HIPCHK(edge_wgrad_launch(dt, 1, tp.up_y[0].back(), tp.A, d_eps, wpart, G(c->out_w), G(c->out_b), B, f.ch[0], f.in_channels, T,
+                             f.f_size, sw));
     // ---- up path, last level first executed = level 0 ... L-1
     const void* gy = w.gA;
     for (int l = 0; l < L; ++l) {
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
+        if (sd.on() && l == knobs().wgrad_flush) CHK(sd.flush_held(s));
         for (int r = f.res[l] - 1; r >= 0; --r) {
             const void* xin = r ? tp.up_y[l][r - 1] : tp.up_in[l];
             void* dx = r == 0 ? w.GS[l] : (gy == w.Gb[l] ? w.Ga[l] : w.Gb[l]);
             const RBW& rbw = c->up_rb[l][r];
             CHK(next_slots());
+            sd.hold = sd.on() && !sd.early && !w.hold[l].empty() ? &w.hold[l][2 * r] : nullptr;
             CHK(run_resblock_bwd(dt, C, xin, tp.up_rb[l][r], gy, nullptr, dx, pf(c, packed, rbw.g0), pf(c, packed, rbw.g1),
                                  pf(c, packed, rbw.g2), pb + bp.up_wd0[l][r], pb + bp.up_wd1[l][r],
-                                 rb_grads(rbw, w.dtemb + c->emb_off_up[up_bi(f, L, l, r)]), rw, B, H, W, s));
+                                 rb_grads(rbw, w.dtemb + c->emb_off_up[up_bi(f, L, l, r)]), rw, B, H, W, s, &sd));
             gy = dx;
         }
+        sd.hold = nullptr;
         // now GS[l] = d(up_in[l]) = gradient of the skip D_l as well
         if (l < L - 1) {
             const int Cn = f.ch[l + 1];
             // up_in[l] = ConvTranspose2d(up_y[l+1].back()) + D_l
-            CHK(run_wgrad(dt, DOWN4, C, Cn, w.GS[l], tp.up_y[l + 1].back(), nullptr, nullptr, XF_NONE, w.partial, G(c->up_w[l + 1]), B,
-                          H / 2, W / 2, s));
+            if (sd.on()) CHK(sd.fork(s));  // (GS[l] is not written again in this call)
+            CHK(run_wgrad(dt, DOWN4, C, Cn, w.GS[l], tp.up_y[l + 1].back(), nullptr, nullptr, XF_NONE, wpart, G(c->up_w[l + 1]), B,
+                          H / 2, W / 2, sw));
             CHK(channel_sums(dt, w.GS[l], w, G(c->up_b[l + 1]), B, H * W, C, s));
             ConvCall d = {dt, DOWN4, C, Cn, w.GS[l], pb + bp.up_dg[l + 1], nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, nullptr,
                           w.Ga[l + 1], nullptr, B, H, W};
@@ -1855,7 +1998,11 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
         HIPCHK(colsum_multi_launch(defer, s));
         defer.count = 0;
         deferred_blocks = 0;
-        HIPCHK(hipEventRecord((hipEvent_t)bucket_events[0], s));
+    }
+    if (sd.on()) CHK(sd.flush_held(s));  // the held weight gradients of the up path: now, under the bottleneck's launch-bound kernels
+    if (n_events) {
+        if (sd.on()) CHK(sd.fork(s));  // the chain does not wait for the branch here: the event goes behind both on the branch's stream
+        HIPCHK(hipEventRecord((hipEvent_t)bucket_events[0], sw));
     }
     // ---- bottleneck: up_in[L-1] = D_{L-1} + O
     const int S = T >> (L - 1), CL = f.ch[L - 1];
@@ -1877,13 +2024,14 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
             CHK(next_slots());
             CHK(run_resblock_bwd(dt, C, xin, tp.dn_rb[l][r], gy, (l == 0 && r == 0) ? w.gA : nullptr, dx, pf(c, packed, rbw.g0),
                                  pf(c, packed, rbw.g1), pf(c, packed, rbw.g2), pb + bp.dn_wd0[l][r], pb + bp.dn_wd1[l][r],
-                                 rb_grads(rbw, w.dtemb + c->emb_off_down[down_bi(f, l, r)]), rw, B, H, W, s));
+                                 rb_grads(rbw, w.dtemb + c->emb_off_down[down_bi(f, l, r)]), rw, B, H, W, s, &sd));
             gy = dx;
         }
         if (l > 0) {
             const int Cp = f.ch[l - 1];
             // dn_in[l] = Conv2d(D_{l-1}, k4 s2 p1)
-            CHK(run_wgrad(dt, DOWN4, Cp, C, tp.dn_y[l - 1].back(), gy, nullptr, nullptr, XF_NONE, w.partial, G(c->down_w[l]), B, H, W, s));
+            if (sd.on()) CHK(sd.fork(s));  // (level l's gradient buffers are not written again in this call)
+            CHK(run_wgrad(dt, DOWN4, Cp, C, tp.dn_y[l - 1].back(), gy, nullptr, nullptr, XF_NONE, wpart, G(c->down_w[l]), B, H, W, sw));
             CHK(channel_sums(dt, gy, w, G(c->down_b[l]), B, H * W, C, s));
             ConvCall u = {dt, UP4, C, Cp, gy, pb + bp.down_dg[l], nullptr, nullptr, 0, nullptr, nullptr, XF_NONE, 0, w.GS[l - 1],
                           w.Ga[l - 1], nullptr, B, H, W};
@@ -1900,6 +2048,7 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
     HIPCHK(linear_bwd_w_launch(w.dh2, tp.temb_h1p, nullptr, G(c->tw[1]), G(c->tb[1]), B, 512, 512, 1, s));
     HIPCHK(linear_bwd_x_launch(w.dh2, pf(c, packed, c->tw[1]), tp.temb_h1p, w.dh1, B, 512, 512, s));
     HIPCHK(linear_bwd_w_launch(w.dh1, pf(c, packed, c->te), t, G(c->tw[0]), G(c->tb[0]), B, 512, 128, 0, s));
+    if (sd.on()) CHK(sd.join(s));
     if (n_events) HIPCHK(hipEventRecord((hipEvent_t)bucket_events[2], s));  // bucket 2: temb.* and down_modules.*
     return 0;
 }

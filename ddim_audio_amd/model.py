@@ -273,6 +273,12 @@ class _UNetTrainFn(torch.autograd.Function):
             g = d_eps.contiguous()
             sync = getattr(model, "grad_sync", None)
             staged = getattr(sync, "staged", None) if sync is not None else None
+            # the weight gradients run on a second stream beside the data-gradient chain (ddimx_unet_bwd_forked; bit-identical
+            # results).  Eager calls use the model's own event set; a capture uses the set of whoever captures (never shared)
+            fc = None
+            if model.bwd_fork:
+                fc = model._capture_bwd_ctx if torch.cuda.is_current_stream_capturing() else model._eager_bwd_context(x.device)
+            side = (ctypes.c_void_p(fc.aux.cuda_stream), fc.event_array(), len(fc.events)) if fc is not None else (None, None, 0)
             if staged is not None and sync.active():
                 # data parallel with overlap: the backward records an event per gradient bucket (up path, bottleneck, the rest)
                 # and each bucket's all-reduce is issued on a side stream as soon as its event has fired, while the remaining
@@ -286,15 +292,16 @@ class _UNetTrainFn(torch.autograd.Function):
                 rng = (ctypes.c_longlong * 6)()
                 _lib.check(lib.ddimx_grad_buckets(model._handle, rng))
                 arr = (ctypes.c_void_p * 3)(*[e.cuda_event for e in evs])
-                _lib.check(lib.ddimx_unet_bwd_staged(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb),
+                _lib.check(lib.ddimx_unet_bwd_forked(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb),
                                                      _lib.ptr(ws), ws.numel(), _lib.ptr(ctx.tape), ctx.tape.numel(), _lib.ptr(x),
                                                      _lib.ptr(ctx.t), _lib.ptr(g), _lib.ptr(flat), b, t_len, ctx.p, ctx.seed, arr, 3,
-                                                     _lib.stream()))
+                                                     _lib.stream(), *side))
                 staged(flat, [(rng[2 * i], rng[2 * i + 1]) for i in range(3)], evs)
             else:
-                _lib.check(lib.ddimx_unet_bwd(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb), _lib.ptr(ws),
-                                              ws.numel(), _lib.ptr(ctx.tape), ctx.tape.numel(), _lib.ptr(x), _lib.ptr(ctx.t), _lib.ptr(g),
-                                              _lib.ptr(flat), b, t_len, ctx.p, ctx.seed, _lib.stream()))
+                _lib.check(lib.ddimx_unet_bwd_forked(model._handle, _lib.ptr(ctx.packed), _lib.ptr(ctx.packed_bwd), ctypes.byref(tb),
+                                                     _lib.ptr(ws), ws.numel(), _lib.ptr(ctx.tape), ctx.tape.numel(), _lib.ptr(x),
+                                                     _lib.ptr(ctx.t), _lib.ptr(g), _lib.ptr(flat), b, t_len, ctx.p, ctx.seed, None, 0,
+                                                     _lib.stream(), *side))
                 if sync is not None:
                     sync(flat)  # data parallel: average the whole gradient buffer over ranks
         ctx.tape = None
@@ -329,6 +336,8 @@ class Model(_Node):
         self._temb_buf = None   # [n_timesteps, E] eval-mode BetaEmbedding table: allocated once, rebuilt in place on a repack
         self._temb_table = None  # = _temb_buf while it is valid for the packed weights (eval mode), else None
         self._eager_fork = None  # ForkContext of the eager (non-captured) forked forwards
+        self._eager_bwd_fork = None   # ... and of the eager backwards (weight gradients on a second stream: ddimx_unet_bwd_forked)
+        self._capture_bwd_ctx = None  # set by train.GraphedTrainStep around its capture: the captured backward's own ForkContext
         # generation of the device buffers a captured graph holds raw pointers to (packed weights, embedding table, tables,
         # workspaces): bumped whenever one of them is re-allocated; a capturer compares it before every replay
         # (sampler.DDIMStepper) and re-captures instead of replaying pointers of an earlier generation
@@ -339,6 +348,7 @@ class Model(_Node):
         # gives nothing, although per-op microbenchmarks say the deep levels alone prefer whole-batch launches.
         import os
         self.fork_mask = int(os.environ.get("DDIMX_FORK_MASK", hex(((1 << len(config.model.ch)) - 1) | 0x10000)), 0)
+        self.bwd_fork = True  # False: the backward stays on one stream
         if dev == "cuda":
             self.to("cuda")  # like nn.Module.type("torch.cuda.FloatTensor") in the reference (:234-235)
 
@@ -356,7 +366,7 @@ class Model(_Node):
         # nothing a live graph still points at: a capturer holds its own references (captured_refs) and sees the new
         # generation before its next replay.
         self._dirty = True
-        self._eager_fork = None
+        self._eager_fork = self._eager_bwd_fork = None
         self._tables = {}
         self._workspace = None
         self._packed = None
@@ -503,6 +513,20 @@ class Model(_Node):
         """A ForkContext for ONE graph capture (owned by the capturer); shares the model's aux stream."""
         ef = self._eager_context(device)
         return ForkContext(device, len(ef.events), aux=ef.aux)
+
+    def new_bwd_fork_context(self, device):
+        """A ForkContext for the backward inside ONE graph capture (``train.GraphedTrainStep`` owns it and sets
+        ``_capture_bwd_ctx`` around its capture); shares the model's weight-gradient stream."""
+        ef = self._eager_bwd_context(device)
+        return ForkContext(device, len(ef.events), aux=ef.aux)
+
+    def _eager_bwd_context(self, device):
+        ef = self._eager_bwd_fork
+        if ef is None or ef.device != device:
+            from . import _lib
+            with torch.cuda.device(device):
+                ef = self._eager_bwd_fork = ForkContext(device, int(_lib.load().ddimx_bwd_side_events(self._handle)))
+        return ef
 
     def _eager_context(self, device):
         ef = self._eager_fork

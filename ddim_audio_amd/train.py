@@ -203,6 +203,10 @@ class GraphedTrainStep:
             # host-built tables (posenc, DFT) must exist before the capture: building them is a host-to-device copy.  (Nothing else is
             # prepared here: the weight re-pack must stay INSIDE the captured forward, every replay follows an optimizer step.)
             self.model._ensure_tables(x.size(2), dev)
+        # the captured backward forks its weight gradients onto a second stream (ddimx_unet_bwd_forked): this capture's own event set
+        self._bwd_ctx = None
+        if getattr(self.model, "bwd_fork", False) and hasattr(self.model, "new_bwd_fork_context"):
+            self._bwd_ctx = self.model.new_bwd_fork_context(dev)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         # The device-scalar hooks exist only while the capture runs: the optimizers read (lr, bias corrections) from _d_dyn and
@@ -216,11 +220,13 @@ class GraphedTrainStep:
         self.model._dropout_ctr_dev = self._d_ctr
         _lib.check(_lib.load().ddimx_set_dropout_counter(self.model._handle, _lib.ptr(self._d_ctr)))
         self.model._alias_leaves = True
+        self.model._capture_bwd_ctx = self._bwd_ctx
         try:
             with torch.cuda.graph(g, stream=self._side):
                 self.loss, self.norms = train_step(self.model, self.x, self.state, self.alphas, e=self.e, t=self.t, _assign_grads=True)
         finally:
             self.model._alias_leaves = False
+            self.model._capture_bwd_ctx = None
             for o in self.state.optimizers.values():
                 o.dyn = None
             self.model._dropout_ctr_dev = None
@@ -244,12 +250,14 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             del g
         self._refs = None
+        self._bwd_ctx = None
 
     def __del__(self):
         try:
             g, self.graph = self.graph, None
             del g
             self._refs = None
+            self._bwd_ctx = None
         except Exception:
             pass
 

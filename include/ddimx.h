@@ -158,6 +158,19 @@ int ddimx_unet_bwd_staged(ddimx_handle h, const void* packed, const void* packed
                           long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
                           const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed,
                           void* const* bucket_events, int n_events, void* stream);
+/* The same backward with its weight gradients on a second stream (runners/diffusion.py:150 `loss.backward()`; autograd has no
+ * counterpart -- it runs one stream).  A conv's weight gradient feeds nothing but its parameter's slot, so it leaves the
+ * data-gradient chain: each is issued on `side_stream` behind an event of `side_events` (caller-owned hipEvent_t, at least
+ * ddimx_bwd_side_events(h) of them, none re-recorded within one call so that the call can be captured into a hipGraph) while the
+ * chain goes on; the branch is joined into `stream` before the call returns.  Results are bit-identical to ddimx_unet_bwd_staged
+ * (same kernels, partitions and order of additions).  With n_events = 3, bucket 0's event is recorded on `side_stream` (behind the
+ * up path's last weight gradient and the chain's batch sums), buckets 1 and 2 on `stream`.  side_stream null: one stream. */
+int ddimx_bwd_side_events(ddimx_handle h);
+int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed_bwd, const ddimx_tables* tables, void* workspace,
+                          long long workspace_bytes, const void* tape, long long tape_bytes, const float* x, const int64_t* t,
+                          const float* d_eps, float* grads, int B, int T, float dropout_p, unsigned long long seed,
+                          void* const* bucket_events, int n_events, void* stream, void* side_stream, void* const* side_events,
+                          int n_side_events);
 /* backward of the per-sample squared-error loss (functions/losses.py:18): d_out[b] = 2 g[b] (out[b] - e[b]) */
 int ddimx_sqerr_loss_bwd(const float* e, const float* out, const float* g_per_sample, float* d_out, int B,
                          long long per_sample, void* stream);

@@ -534,6 +534,46 @@ def test_staged_backward_buckets_are_final_when_their_event_fires():
 
 
 @pytest.mark.parametrize("mode", MODES, ids=["f32", "bf16"])
+def test_forked_backward_is_bit_identical_to_the_one_stream_backward(mode):
+    """ddimx_unet_bwd_forked: the weight gradients leave the data-gradient chain for a second stream (each behind an event, reading
+    the branch's own two ``du`` buffers, which the chain may only overwrite behind the event of their last reader).  Same kernels,
+    same partitions, same order of additions: every gradient must carry the bits of the one-stream backward -- at two shapes (so
+    that both the full-chip and the launch-bound levels race if anything can), five times over with the gradient buffer and the
+    workspace poisoned in between, and with kernels of another stream in flight."""
+    dtype_str, dt = mode
+    cfg, m = _train_model(dtype_str)
+    alphas = make_schedule(cfg.diffusion)[1].cuda()
+    for shape, tt in (((4, 2, 256, 256), [5, 994, 300, 650]), ((2, 2, 32, 256), [0, 999])):
+        x0, e = synth.gaussian("bwdfork.x0", shape).cuda(), synth.gaussian("bwdfork.e", shape).cuda()
+        t = torch.tensor(tt).cuda()
+        m.bwd_fork = False
+        loss = losses.noise_estimation_loss(m, x0, t, e, alphas)
+        m._train_ws.fill_(0xFF)  # the backward takes nothing from the forward's scratch: the tape holds what it needs
+        loss.backward()
+        plain = {n: p.grad.clone() for n, p in m.named_parameters()}
+        assert all(bool(torch.isfinite(g).all()) for g in plain.values())
+        lib = __import__("ddim_audio_amd")._lib.load()
+        assert int(lib.ddimx_bwd_side_events(m._handle)) == 4 * 2 * sum(cfg.model.res) + 2 * (len(cfg.model.ch) - 1) + 3
+        m.zero_grad(set_to_none=True)
+        m.bwd_fork = True
+        other = torch.cuda.Stream()
+        junk = torch.randn(1 << 22, device="cuda")
+        for rep in range(5):
+            m._flat_grad.fill_(float("nan"))
+            loss = losses.noise_estimation_loss(m, x0, t, e, alphas)
+            m._train_ws.fill_(0xFF)  # NaN patterns in every buffer of the backward, `du` and the slabs included
+            if rep % 2:
+                with torch.cuda.stream(other):
+                    for _ in range(20):
+                        junk = junk * 1.0001
+            loss.backward()
+            torch.cuda.synchronize()
+            for n, p in m.named_parameters():
+                assert torch.equal(p.grad, plain[n]), (shape, rep, n)
+            m.zero_grad(set_to_none=True)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["f32", "bf16"])
 def test_forked_forward_is_bit_identical_for_every_mask(mode):
     """ddimx_unet_fwd_forked: any subset of levels / the FNet run as two batch shards on two streams must give the bits of the
     plain forward (every op is per sample, the launch plan depends on the sample's size only) -- eagerly, for an odd batch,
