@@ -1134,6 +1134,8 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         if (++batch.count == PackCopyBatch::kMax) { hipError_t e = pack_copy_multi_launch(batch, s); batch.count = 0; return e; }
         return hipSuccess;
     };
+    PackConvBatch convs;  // ... and the conv weights likewise (64 per launch)
+    convs.count = 0;
     for (int i = 0; i < n_params; ++i) {
         const ParamSpec& p = h->specs[i];
         const float* src = (const float*)params[i];
@@ -1141,10 +1143,8 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         if (!src) return fail("ddimx_pack_weights: parameter %d (%s) is null", i, p.name.c_str());
         switch (p.kind) {
             case PK_COPY: HIPCHK(push_copy(src, (float*)dst, p.numel)); break;
-            case PK_CONV:
-                HIPCHK(pack_conv_launch(h->dtype, src, dst, p.d0, p.d1, p.d2, p.d3, s));
-                break;
-            case PK_CONV_F32: HIPCHK(pack_conv_launch(DT_F32, src, dst, p.d0, p.d1, p.d2, p.d3, s)); break;
+            case PK_CONV: HIPCHK(convs.push(src, dst, p.d0, p.d1, p.d2 * p.d3, 0, h->dtype, s)); break;
+            case PK_CONV_F32: HIPCHK(convs.push(src, dst, p.d0, p.d1, p.d2 * p.d3, 0, DT_F32, s)); break;
             case PK_CONVT:
                 HIPCHK(pack_convT_launch(h->dtype, src, dst, p.d0, p.d1, s));
                 break;
@@ -1158,6 +1158,7 @@ int ddimx_pack_weights(ddimx_handle h, const void* const* params, int n_params, 
         }
     }
     HIPCHK(pack_copy_multi_launch(batch, s));
+    HIPCHK(pack_conv_multi_launch(convs, s));
     return 0;
 }
 
@@ -1750,21 +1751,24 @@ int ddimx_pack_weights_bwd(ddimx_handle h, const void* const* params, int n_para
     plan_bwd_pack(c, &b);
     char* base = (char*)packed_bwd;
     const int dt = c->dtype;
+    PackConvBatch convs;  // all conv packings of the backward in two launches (pack_conv_multi_kernel)
+    convs.count = 0;
     for (int l = 0; l < c->L; ++l) {
         const int C = f.ch[l];
         for (int r = 0; r < f.res[l]; ++r) {
-            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->down_rb[l][r].w0], base + b.dn_wd0[l][r], C, C, s));
-            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->down_rb[l][r].w1], base + b.dn_wd1[l][r], C, C, s));
-            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->up_rb[l][r].w0], base + b.up_wd0[l][r], C, C, s));
-            HIPCHK(pack_conv_dgrad_launch(dt, (const float*)params[c->up_rb[l][r].w1], base + b.up_wd1[l][r], C, C, s));
+            HIPCHK(convs.push((const float*)params[c->down_rb[l][r].w0], base + b.dn_wd0[l][r], C, C, 9, 1, dt, s));
+            HIPCHK(convs.push((const float*)params[c->down_rb[l][r].w1], base + b.dn_wd1[l][r], C, C, 9, 1, dt, s));
+            HIPCHK(convs.push((const float*)params[c->up_rb[l][r].w0], base + b.up_wd0[l][r], C, C, 9, 1, dt, s));
+            HIPCHK(convs.push((const float*)params[c->up_rb[l][r].w1], base + b.up_wd1[l][r], C, C, 9, 1, dt, s));
         }
         if (l > 0) {
             // d(input) of Conv2d(W [C][Cprev][4][4], s2 p1) = ConvTranspose2d with the same tensor read as [I = C][O = Cprev]
             HIPCHK(pack_convT_launch(dt, (const float*)params[c->down_w[l]], base + b.down_dg[l], C, f.ch[l - 1], s));
             // d(input) of ConvTranspose2d(W [C][Cprev][4][4]) = Conv2d with the same tensor read as [O = C][I = Cprev]
-            HIPCHK(pack_conv_launch(dt, (const float*)params[c->up_w[l]], base + b.up_dg[l], C, f.ch[l - 1], 4, 4, s));
+            HIPCHK(convs.push((const float*)params[c->up_w[l]], base + b.up_dg[l], C, f.ch[l - 1], 16, 0, dt, s));
         }
     }
+    HIPCHK(pack_conv_multi_launch(convs, s));
     const int hid = f.fnet_hidden, inter = f.fnet_inter, width = c->width;
     HIPCHK(transpose_launch(pf(c, packed, c->proj_w), (float*)(base + b.projT), hid, width, 0, s));   // [hid][width] -> [width][hid]
     HIPCHK(transpose_launch(pf(c, packed, c->cout_w), (float*)(base + b.coutT), width, hid, 0, s));   // [width][hid] -> [hid][width]

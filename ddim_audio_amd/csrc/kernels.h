@@ -151,6 +151,19 @@ struct PackCopyBatch {
     const float* src[kMax]; float* dst[kMax]; long long n[kMax]; int count;
 };
 hipError_t pack_copy_multi_launch(const PackCopyBatch& b, hipStream_t s);
+struct PackConvBatch {
+    static constexpr int kMax = 64;
+    const float* src[kMax]; void* dst[kMax]; int O[kMax], I[kMax], KK[kMax]; unsigned char mode[kMax], f32[kMax]; int count;
+    // queues one packing; launches the batch when it is full
+    hipError_t push(const float* w, void* d, int o, int i, int kk, int md, int dtype, hipStream_t s);
+};
+hipError_t pack_conv_multi_launch(const PackConvBatch& b, hipStream_t s);
+inline hipError_t PackConvBatch::push(const float* w, void* d, int o, int i, int kk, int md, int dtype, hipStream_t s) {
+    src[count] = w; dst[count] = d; O[count] = o; I[count] = i; KK[count] = kk; mode[count] = (unsigned char)md;
+    f32[count] = dtype == DT_F32;
+    if (++count == kMax) { hipError_t e = pack_conv_multi_launch(*this, s); count = 0; return e; }
+    return hipSuccess;
+}
 hipError_t pack_conv_launch(int dtype, const float* w /*[O][I][KH][KW]*/, void* dst /*[KH*KW][O][I]*/, int O, int I,
                             int KH, int KW, hipStream_t s);
 hipError_t pack_convT_launch(int dtype, const float* w /*[I][O][4][4]*/, void* dst /*[2][6][2*O][I]*/, int I, int O,

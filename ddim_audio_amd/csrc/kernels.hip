@@ -1240,6 +1240,39 @@ hipError_t pack_conv_launch(int dtype, const float* w, void* dst, int O, int I, 
     return hipGetLastError();
 }
 
+// many conv-weight packings in one launch (a training step re-packs every conv after its optimizer step: 143 launches of 4 us
+// otherwise).  mode 0: the forward layout of pack_conv_kernel, dst[tap][co][ci] = w[co][ci][tap]; mode 1: the data-gradient
+// packing of a 3x3 conv (train_kernels.hip: transposed and flipped), dst[tp][ci][co] = w[co][ci][8 - tp].
+template <typename T>
+__device__ __forceinline__ void pack_conv_entry(const float* __restrict__ w, T* __restrict__ dst, int O, int I, int KK, int mode) {
+    const int n = KK * O * I;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (mode == 0) {
+            const int ci = i % I, co = (i / I) % O, tap = i / (I * O);
+            dst[i] = from_f<T>(w[((size_t)co * I + ci) * KK + tap]);
+        } else {
+            const int co = i % O, ci = (i / O) % I, tp = i / (O * I);
+            dst[i] = from_f<T>(w[((size_t)co * I + ci) * 9 + (8 - tp)]);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) pack_conv_multi_kernel(const PackConvBatch b) {
+    const int e = blockIdx.y;
+    if (b.f32[e]) pack_conv_entry<float>(b.src[e], (float*)b.dst[e], b.O[e], b.I[e], b.KK[e], b.mode[e]);
+    else pack_conv_entry<__bf16>(b.src[e], (__bf16*)b.dst[e], b.O[e], b.I[e], b.KK[e], b.mode[e]);
+}
+hipError_t pack_conv_multi_launch(const PackConvBatch& b, hipStream_t s) {
+    if (b.count < 1) return hipSuccess;
+    long long mx = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const long long n = (long long)b.KK[i] * b.O[i] * b.I[i];
+        if (n > mx) mx = n;
+    }
+    const int bx = (int)((mx + 255) / 256 < 64 ? (mx + 255) / 256 : 64);
+    hipLaunchKernelGGL(pack_conv_multi_kernel, dim3(bx, b.count), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
 // conv weight [O][I][KH][KW] fp32 (KK = KH * KW taps, row-major) -> bf16 in MFMA fragment order (conv_wreg.h):
 //   dst[step = tap * (I/16) + kg][nb][lane = h * 32 + l31][j]  =  w[co = nb * 32 + l31][ci = kg * 16 + h * 8 + j][tap]
 __global__ void pack_conv_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int O, int I, int KK) {
