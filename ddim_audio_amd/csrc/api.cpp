@@ -33,7 +33,9 @@ struct Knobs {
         // backward, whose launch-bound FNet kernels leave the chip idle (WgSide::held)
         wgrad_hold = geti("DDIMX_WGRAD_HOLD", 2);
         wgrad_flush = geti("DDIMX_WGRAD_FLUSH", 99);  // A/B: issue the held ones when the up path's backward enters this level (default: at the FNet)
-        bwd_stats_fused = geti("DDIMX_BWD_STATS_FUSED", 1);  // A/B: 0 = GroupNorm-backward statistics by their own pass
+        // A/B, GroupNorm-backward statistics -- bit 0: of GN1 / GN0 in the data-gradient convs' epilogue, bit 1: of GN2 in the previous
+        // block's last apply pass; 0 = every statistics pass on its own
+        bwd_stats_fused = geti("DDIMX_BWD_STATS_FUSED", 3);
         gn_dbg = geti("DDIMX_GN_DBG", 0);          // tools/gn_dbg.sh: 1 = resid, 2 = convs take their GroupNorm input from a finalize launch
         fnet_dense = geti("DDIMX_FNET_DENSE", 1);  // tools/fnet_ab.sh: 0 = the GEMM path for the FNet at S <= 32
         conv_wreg = geti("DDIMX_CONV_WREG", 1);    // tools/step_ab.sh: 0 = the convs of C >= 64 keep the LDS weight ring (conv_mfma_kernel)
@@ -874,7 +876,8 @@ static size_t rb_bwd_stats_floats(int dtype, int B, int HW, int C) { return (siz
 // gradients are WRITTEN (not accumulated).  wd0 / wd1: data-gradient packings of conv.0 / conv.1.
 static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, const void* dy, const void* extra, void* dx,
                             const float* gam0, const float* gam1, const float* gam2, const void* wd0, const void* wd1,
-                            const RBGrads& gr, const RBBwdWs& w, int B, int H, int W, hipStream_t s, WgSide* sd = nullptr) {
+                            const RBGrads& gr, const RBBwdWs& w, int B, int H, int W, hipStream_t s, WgSide* sd = nullptr,
+                            bool stats_ready = false, const void* next_u2 = nullptr) {
     const int HW = H * W;
     const double cnt = (double)HW * (C / kGroups);
     const int np = resid_nparts(dtype, HW, C);
@@ -898,7 +901,8 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     float* const dgb1 = w.slots ? slot0 + 2 * slot_f : w.dgb;
     float* const dgb0 = w.slots ? slot0 + 3 * slot_f : w.dgb;
     // ---- GN2 (fed by SiLU(u2), weight only) and the SiLU in front of it: du2
-    HIPCHK(gn_bwd_stats_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.stats, B, HW, C, s));
+    // (stats_ready: the kernel that produced dy -- the previous block's last apply pass -- has left these slabs in w.stats)
+    if (!stats_ready) HIPCHK(gn_bwd_stats_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.stats, B, HW, C, s));
     HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam2, tp.mr(2, B, C), w.coef, dgb2, B, s));
     CHK(push_colsum(w, dgb2, B, 2 * C, C, gr.g2, s));
     if (side && !hold) CHK(sd->claim(par, s));
@@ -914,7 +918,7 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
         ConvPlan pl;
         CHK(conv_plan(d, &pl));
         *nparts = pl.wgs_per_sample * pl.g.classes;
-        if (knobs().bwd_stats_fused == 0 || *nparts > np) { *nparts = 0; return 0; }  // (slabs are sized for resid's partition)
+        if (!(knobs().bwd_stats_fused & 1) || *nparts > np) { *nparts = 0; return 0; }  // (slabs are sized for resid's partition)
         d.aux = aux; d.aux_scale = asc; d.aux_shift = ash; d.bwd_mode = mode; d.stats = w.stats;
         return 0;
     };
@@ -950,7 +954,9 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     HIPCHK(gn_bwd_finalize_launch(w.stats, np0, C, cnt, gam0, tp.mr(0, B, C), w.coef, dgb0, B, s));
     CHK(push_colsum(w, dgb0, B, 2 * C, C, gr.g0, s));
     CHK(push_colsum(w, dgb0 + C, B, 2 * C, C, gr.b0, s));
-    HIPCHK(gn_bwd_apply_launch(dtype, 1, w.dg, x, dy, extra, w.coef, tp.sc(0, B, C), tp.sh(0, B, C), dx, nullptr, B, HW, C, s));
+    // next_u2: dx is the dy of a block of the same shape whose saved u2 this is -- its first statistics pass rides this kernel
+    HIPCHK(gn_bwd_apply_launch(dtype, 1, w.dg, x, dy, extra, w.coef, tp.sc(0, B, C), tp.sh(0, B, C), dx, nullptr, B, HW, C, s,
+                               next_u2, next_u2 ? w.stats : nullptr));
     return 0;
 }
 
@@ -1969,6 +1975,8 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
                              f.f_size, sw));
     // ---- up path, last level first executed = level 0 ... L-1
     const void* gy = w.gA;
+    const bool chain_stats = (knobs().bwd_stats_fused & 2) != 0;
+    bool have_stats = false;  // w.stats holds the first statistics pass of the block about to run
     for (int l = 0; l < L; ++l) {
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
         if (sd.on() && l == knobs().wgrad_flush) CHK(sd.flush_held(s));
@@ -1978,9 +1986,12 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
             const RBW& rbw = c->up_rb[l][r];
             CHK(next_slots());
             sd.hold = sd.on() && !sd.early && !w.hold[l].empty() ? &w.hold[l][2 * r] : nullptr;
+            // (block r - 1 of the level takes dx as its dy: its first statistics pass rides this block's last kernel)
+            const void* nu2 = chain_stats && r > 0 ? tp.up_rb[l][r - 1].u2 : nullptr;
             CHK(run_resblock_bwd(dt, C, xin, tp.up_rb[l][r], gy, nullptr, dx, pf(c, packed, rbw.g0), pf(c, packed, rbw.g1),
                                  pf(c, packed, rbw.g2), pb + bp.up_wd0[l][r], pb + bp.up_wd1[l][r],
-                                 rb_grads(rbw, w.dtemb + c->emb_off_up[up_bi(f, L, l, r)]), rw, B, H, W, s, &sd));
+                                 rb_grads(rbw, w.dtemb + c->emb_off_up[up_bi(f, L, l, r)]), rw, B, H, W, s, &sd, have_stats, nu2));
+            have_stats = nu2 != nullptr;
             gy = dx;
         }
         sd.hold = nullptr;
@@ -2026,9 +2037,11 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
             void* dx = gy == w.Gb[l] ? w.Ga[l] : w.Gb[l];
             const RBW& rbw = c->down_rb[l][r];
             CHK(next_slots());
+            const void* nu2 = chain_stats && r > 0 ? tp.dn_rb[l][r - 1].u2 : nullptr;
             CHK(run_resblock_bwd(dt, C, xin, tp.dn_rb[l][r], gy, (l == 0 && r == 0) ? w.gA : nullptr, dx, pf(c, packed, rbw.g0),
                                  pf(c, packed, rbw.g1), pf(c, packed, rbw.g2), pb + bp.dn_wd0[l][r], pb + bp.dn_wd1[l][r],
-                                 rb_grads(rbw, w.dtemb + c->emb_off_down[down_bi(f, l, r)]), rw, B, H, W, s, &sd));
+                                 rb_grads(rbw, w.dtemb + c->emb_off_down[down_bi(f, l, r)]), rw, B, H, W, s, &sd, have_stats, nu2));
+            have_stats = nu2 != nullptr;
             gy = dx;
         }
         if (l > 0) {

@@ -13,10 +13,11 @@ hipError_t gn_bwd_stats_launch(int dtype, int mode, const void* g, const void* u
 hipError_t gn_bwd_finalize_launch(const float* stats, int nparts, int C, double count, const float* gamma, const float* mr,
                                   float* coef, float* dgb, int B, hipStream_t s);
 // mode 0: out = (ca*g + cb*SiLU(u) + cc)*SiLU'(u), sums [B][nparts][C] of out (nullable)
-// mode 1: out = gy + ca*(g*SiLU'(scale*u+shift)) + cb*u + cc (+ extra)
+// mode 1: out = gy + ca*(g*SiLU'(scale*u+shift)) + cb*u + cc (+ extra); with nstats (and nu) also the slabs gn_bwd_stats_launch(mode 0)
+//         would write for (g = out, u = nu): the first statistics pass of the block that takes `out` as its dy, bit for bit
 hipError_t gn_bwd_apply_launch(int dtype, int mode, const void* g, const void* u, const void* gy, const void* extra,
                                const float* coef, const float* scale, const float* shift, void* out, float* sums, int B,
-                               int HW, int C, hipStream_t s);
+                               int HW, int C, hipStream_t s, const void* nu = nullptr, float* nstats = nullptr);
 hipError_t colsum_launch(const float* src, int B, long long stride, int C, float* dst, hipStream_t s);
 struct ColsumBatch {
     static constexpr int kMax = 96;

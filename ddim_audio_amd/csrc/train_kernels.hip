@@ -350,19 +350,29 @@ hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst
 // GroupNorm backward, step 3 (elementwise):
 //   MODE 0:  du = (ca*g + cb*SiLU(u) + cc) * SiLU'(u)                 + per-(sample, part, channel) sums of du
 //   MODE 1:  dx = gy + ca*(g*SiLU'(scale*x+shift)) + cb*x + cc [+ extra]          (x = u)
+//            + (nstats != null) the first statistics pass of the block that reads dx as ITS dy: P = sum dx, Q = sum dx * SiLU(nu),
+//              nu = that block's saved u2 -- same partition, same per-thread order of additions and the same rounded dx values as
+//              gn_bwd_stats_kernel<T, 0> over (dx, nu), so the slabs are bit-identical to that pass and it need not run
 // =====================================================================================================
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ u,
                                                            const T* __restrict__ gy, const T* __restrict__ extra,
                                                            const float* __restrict__ coef, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ out,
-                                                           float* __restrict__ sums, int HW, int C, int iters) {
+                                                           float* __restrict__ sums, int HW, int C, int iters,
+                                                           const T* __restrict__ nu, float* __restrict__ nstats) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x, bd = blockDim.x;
     const int CPP = C / EPB, c = tid % CPP, b = blockIdx.y, part = blockIdx.x;
     const long long pieces = (long long)HW * CPP;
     float ca[EPB], cb[EPB], cc[EPB], sc[EPB], sh[EPB], acc[EPB];
+    float nP[MODE == 1 ? EPB : 1], nQ[MODE == 1 ? EPB : 1];
+    const bool chain = MODE == 1 && nstats != nullptr;  // uniform
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) nP[j] = nQ[j] = 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < EPB; ++j) {
         const int ch = c * EPB + j;
@@ -380,7 +390,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
     const size_t sbase = (size_t)b * HW * C;
     const T* const pex = (MODE == 1 && extra) ? extra : g;
     for (int it0 = 0; it0 < iters; it0 += NIT) {
-        uint4 vg[NIT], vu[NIT], vy[MODE == 1 ? NIT : 1], ve[MODE == 1 ? NIT : 1];
+        uint4 vg[NIT], vu[NIT], vy[MODE == 1 ? NIT : 1], ve[MODE == 1 ? NIT : 1], vn[MODE == 1 ? NIT : 1];
         size_t e[NIT];
         bool ok[NIT];
 #pragma unroll
@@ -393,6 +403,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
             if (MODE == 1) {
                 vy[k] = *(const uint4*)(gy + e[k]);
                 ve[k] = *(const uint4*)(pex + e[k]);
+                if (chain) vn[k] = *(const uint4*)(nu + e[k]);
             }
         }
 #pragma unroll
@@ -421,6 +432,16 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
             }
             const uint4 pv = Piece<T>::pack(fo);
             *(uint4*)(out + e[k]) = pv;
+            if (MODE == 1 && chain) {
+                float fn[EPB];
+                Piece<T>::unpack(pv, fo);  // the values as stored: what the separate pass would read
+                Piece<T>::unpack(vn[k], fn);
+#pragma unroll
+                for (int j = 0; j < EPB; ++j) {
+                    nP[j] += fo[j];
+                    nQ[j] = fmaf(fo[j], silu_f(fn[j]), nQ[j]);
+                }
+            }
             if (MODE == 0) {
                 Piece<T>::unpack(pv, fo);  // sums of the values as stored (what the weight-gradient kernel will read)
 #pragma unroll
@@ -439,19 +460,34 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
             sums[((size_t)b * gridDim.x + part) * C + i] = t;
         }
     }
+    if (MODE == 1 && chain) {  // exactly gn_bwd_stats_kernel's reduction
+        const int R = bd / CPP, row = tid / CPP;
+#pragma unroll
+        for (int j = 0; j < EPB; ++j) {
+            red[(row * C + c * EPB + j) * 2 + 0] = nP[j];
+            red[(row * C + c * EPB + j) * 2 + 1] = nQ[j];
+        }
+        __syncthreads();
+        for (int i = tid; i < C * 2; i += bd) {
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += red[r * C * 2 + i];
+            nstats[(((size_t)b * gridDim.x + part) * C) * 2 + i] = t;
+        }
+    }
 }
 hipError_t gn_bwd_apply_launch(int dtype, int mode, const void* g, const void* u, const void* gy, const void* extra,
                                const float* coef, const float* scale, const float* shift, void* out, float* sums, int B,
-                               int HW, int C, hipStream_t s) {
+                               int HW, int C, hipStream_t s, const void* nu, float* nstats) {
     const int epb = dtype == DT_BF16 ? 8 : 4;
     if (C % epb) return hipErrorInvalidValue;
     const int cpp = C / epb, bd = tr_bd(cpp);
     if (bd % cpp) return hipErrorInvalidValue;
     dim3 grid(tr_nparts(dtype, HW, C), B);
-    const size_t lds = (size_t)(bd / cpp) * C * 4;
+    if (nstats && (mode != 1 || !nu)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(bd / cpp) * C * 4 * (nstats ? 2 : 1);
 #define DDIMX_L(TT, M)                                                                                                      \
     hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, M>), grid, dim3(bd), lds, s, (const TT*)g, (const TT*)u, (const TT*)gy, \
-                       (const TT*)extra, coef, scale, shift, (TT*)out, sums, HW, C, resid_iters(dtype, HW, C))
+                       (const TT*)extra, coef, scale, shift, (TT*)out, sums, HW, C, resid_iters(dtype, HW, C), (const TT*)nu, nstats)
     if (dtype == DT_BF16) { if (mode) DDIMX_L(__bf16, 1); else DDIMX_L(__bf16, 0); }
     else { if (mode) DDIMX_L(float, 1); else DDIMX_L(float, 0); }
 #undef DDIMX_L
