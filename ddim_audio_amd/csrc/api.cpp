@@ -862,6 +862,11 @@ struct RBBwdWs {
     // a time (colsum_multi); each block then gets its own 4 slots of [B][2][C] floats in `slots` (null: sum immediately)
     ColsumBatch* defer = nullptr;
     float* slots = nullptr;
+    // ... and so are the per-sample channel sums of du2 / du1 (conv.1.bias, the timestep-embedding chunk): each block then writes
+    // them into two slabs of its own (`sums2`: [2][sums floats]) and queues the reductions (partsum_multi)
+    PartsumBatch* pdefer = nullptr;
+    float* sums2 = nullptr;
+    size_t sums_f = 0;
 };
 static int push_colsum(const RBBwdWs& w, const float* src, int B, long long stride, int C, float* dst, hipStream_t s) {
     if (!w.defer) { HIPCHK(colsum_launch(src, B, stride, C, dst, s)); return 0; }
@@ -906,8 +911,18 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     HIPCHK(gn_bwd_finalize_launch(w.stats, np, C, cnt, gam2, tp.mr(2, B, C), w.coef, dgb2, B, s));
     CHK(push_colsum(w, dgb2, B, 2 * C, C, gr.g2, s));
     if (side && !hold) CHK(sd->claim(par, s));
-    HIPCHK(gn_bwd_apply_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.coef, nullptr, nullptr, du2, w.sums, B, HW, C, s));
-    HIPCHK(partsum_launch(w.sums, B, np, C, sumb, C, s));           // per-sample channel sums of du2
+    float* const sums_a = w.pdefer ? w.sums2 : w.sums;
+    float* const sums_b = w.pdefer ? w.sums2 + w.sums_f : w.sums;
+    auto psum = [&](const float* src, float* dst, long long stride) -> int {
+        if (!w.pdefer) { HIPCHK(partsum_launch(src, B, np, C, dst, stride, s)); return 0; }
+        PartsumBatch& q = *w.pdefer;
+        if (q.count >= PartsumBatch::kMax) return fail("partsum queue overflow");
+        q.src[q.count] = src; q.dst[q.count] = dst; q.dst_stride[q.count] = stride; q.nparts[q.count] = np; q.C[q.count] = C; q.B[q.count] = B;
+        ++q.count;
+        return 0;
+    };
+    HIPCHK(gn_bwd_apply_launch(dtype, 0, dy, tp.u2, nullptr, nullptr, w.coef, nullptr, nullptr, du2, sums_a, B, HW, C, s));
+    CHK(psum(sums_a, sumb, C));                                     // per-sample channel sums of du2
     CHK(push_colsum(w, sumb, B, C, C, gr.bias1, s));                // conv.1.bias
     // ---- conv.1: weight gradient against GN1(SiLU(u1)), data gradient -> dg
     if (early) CHK(sd->fork(s));
@@ -931,8 +946,8 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     HIPCHK(gn_bwd_finalize_launch(w.stats, np1, C, cnt, gam1, tp.mr(1, B, C), w.coef, dgb1, B, s));
     CHK(push_colsum(w, dgb1, B, 2 * C, C, gr.g1, s));
     CHK(push_colsum(w, dgb1 + C, B, 2 * C, C, gr.b1, s));
-    HIPCHK(gn_bwd_apply_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.coef, nullptr, nullptr, du1, w.sums, B, HW, C, s));
-    if (gr.dtemb) HIPCHK(partsum_launch(w.sums, B, np, C, gr.dtemb, gr.dtemb_stride, s));  // timestep-embedding chunk
+    HIPCHK(gn_bwd_apply_launch(dtype, 0, w.dg, tp.u1, nullptr, nullptr, w.coef, nullptr, nullptr, du1, sums_b, B, HW, C, s));
+    if (gr.dtemb) CHK(psum(sums_b, gr.dtemb, gr.dtemb_stride));     // timestep-embedding chunk
     // ---- conv.0: weight gradient against SiLU(GN0(x)), data gradient -> dg
     if (early) CHK(sd->fork(s));
     if (!side || early) CHK(wgrad0());
@@ -1493,7 +1508,8 @@ struct TrainWs {
     float *Ut, *Hb, *O, *gpart;
     std::vector<void*> Ga, Gb, GS;
     void *gA, *du, *dg, *du_b[3];          // du_b / partial_b: the weight-gradient branch's further `du` buffers and its own slabs (WgSide)
-    float *coef, *dgb, *sums, *partial, *partial_b, *slots;
+    float *coef, *dgb, *sums, *partial, *partial_b, *slots, *sums_ring;
+    size_t sums_f;
     std::vector<std::vector<void*>> hold;  // [level][2 r + {du2, du1}]: the up path's held weight gradients (WgSide::held)
     float *dtemb, *dh2, *dh1;
     float *dO, *dXa, *dXb, *dZ, *dH, *T1, *T2, *lnpart, *dTok, *pgrad;
@@ -1547,6 +1563,8 @@ static void carve_train_ws(const ddimx_ctx* c, char* base, int B, int T, TrainWs
     w->dgb = (float*)cv.take((size_t)B * 2 * cmax * 4);
     w->slots = (float*)cv.take((size_t)kDeferBlocks * 4 * B * 2 * cmax * 4);
     w->sums = (float*)cv.take(sums_f * 4);
+    w->sums_f = sums_f;
+    w->sums_ring = (float*)cv.take((size_t)kDeferBlocks * 2 * sums_f * 4);
     w->partial = (float*)cv.take(part_f * 4);
     w->partial_b = (float*)cv.take(part_f * 4);
     w->dtemb = (float*)cv.take((size_t)B * c->E * 4);
@@ -1950,16 +1968,27 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
     ColsumBatch defer;
     defer.count = 0;
     rw.defer = &defer;
+    PartsumBatch pdefer;
+    pdefer.count = 0;
+    rw.pdefer = &pdefer;
+    rw.sums_f = w.sums_f;
+    auto flush_sums = [&]() -> int {  // the queued per-sample sums first: some of the batch sums read them
+        HIPCHK(partsum_multi_launch(pdefer, s));
+        pdefer.count = 0;
+        HIPCHK(colsum_multi_launch(defer, s));
+        defer.count = 0;
+        return 0;
+    };
     int deferred_blocks = 0;
     int cmax = 0;
     for (int l = 0; l < L; ++l) if (f.ch[l] > cmax) cmax = f.ch[l];
     auto next_slots = [&]() -> int {  // hands the next block its slots; flushes the batch when the arena is full
         if (deferred_blocks == kDeferBlocks) {
-            HIPCHK(colsum_multi_launch(defer, s));
-            defer.count = 0;
+            CHK(flush_sums());
             deferred_blocks = 0;
         }
         rw.slots = w.slots + (size_t)deferred_blocks * 4 * B * 2 * cmax;
+        rw.sums2 = w.sums_ring + (size_t)deferred_blocks * 2 * w.sums_f;
         ++deferred_blocks;
         return 0;
     };
@@ -2010,8 +2039,7 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
         }
     }
     if (n_events) {  // bucket 0: every up_modules.* gradient is final once the deferred batch sums are flushed
-        HIPCHK(colsum_multi_launch(defer, s));
-        defer.count = 0;
+        CHK(flush_sums());
         deferred_blocks = 0;
     }
     if (sd.on()) CHK(sd.flush_held(s));  // the held weight gradients of the up path: now, under the bottleneck's launch-bound kernels
@@ -2056,7 +2084,7 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
             gy = w.Ga[l - 1];
         }
     }
-    HIPCHK(colsum_multi_launch(defer, s));
+    CHK(flush_sums());
     // ---- input conv (models/diffusion.py:255-256): gy = d(hidden[0]) including the skip into the output conv
     HIPCHK(edge_wgrad_launch(dt, 0, gy, nullptr, x, w.partial, G(c->in_w), G(c->in_b), B, f.ch[0], f.in_channels, T, f.f_size, s));
     // ---- timestep-embedding MLP

@@ -27,6 +27,13 @@ hipError_t colsum_multi_launch(const ColsumBatch& q, hipStream_t s);
 // dst[b][c] = sum_p src[((b*nparts + p)*C + c) * src_step]   (src_step = 2 reads the `sum` half of (sum, sumsq) slabs)
 hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s,
                           int src_step = 1);
+// the same for many (src, dst) pairs in one launch (src_step 1): the backward defers the per-sample channel sums of its blocks
+// (conv.1.bias and timestep-embedding terms: nothing on the data-gradient chain reads them) and flushes them with the batch sums
+struct PartsumBatch {
+    static constexpr int kMax = 32;
+    const float* src[kMax]; float* dst[kMax]; long long dst_stride[kMax]; int nparts[kMax], C[kMax], B[kMax]; int count;
+};
+hipError_t partsum_multi_launch(const PartsumBatch& q, hipStream_t s);
 // data-gradient weights of a 3x3 conv: dst[tap'][ci][co] = w[co][ci][8 - tap'] in the activation dtype
 hipError_t pack_conv_dgrad_launch(int dtype, const float* w, void* dst, int O, int I, hipStream_t s);
 

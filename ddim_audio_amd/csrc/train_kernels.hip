@@ -340,6 +340,43 @@ __global__ void __launch_bounds__(256) partsum_kernel(const float* __restrict__ 
         dst[(size_t)b * dst_stride + c] = (float)s;
     }
 }
+__global__ void __launch_bounds__(256) partsum_multi_kernel(const PartsumBatch q) {
+    __shared__ double red[8][32];
+    const int e = blockIdx.z;
+    const int C = q.C[e], nparts = q.nparts[e];
+    if ((int)blockIdx.y >= q.B[e] || (int)blockIdx.x * 32 >= C) return;  // uniform
+    const float* __restrict__ src = q.src[e];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, b = blockIdx.y;
+    double s = 0.0;
+    {   // partsum_kernel's loop, word for word: the sums carry the same bits
+        const int cs = c < C ? c : C - 1;
+        for (int p0 = rl; p0 < nparts; p0 += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + 8 * u;
+                v[u] = src[((size_t)b * nparts + (p < nparts ? p : nparts - 1)) * C + cs];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (c < C && p0 + 8 * u < nparts) ? (double)v[u] : 0.0;
+        }
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s = 0.0;
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        q.dst[e][(size_t)b * q.dst_stride[e] + c] = (float)s;
+    }
+}
+hipError_t partsum_multi_launch(const PartsumBatch& q, hipStream_t s) {
+    if (q.count < 1) return hipSuccess;
+    int cm = 0, bm = 0;
+    for (int i = 0; i < q.count; ++i) { if (q.C[i] > cm) cm = q.C[i]; if (q.B[i] > bm) bm = q.B[i]; }
+    hipLaunchKernelGGL(partsum_multi_kernel, dim3((cm + 31) / 32, bm, q.count), dim3(256), 0, s, q);
+    return hipGetLastError();
+}
 hipError_t partsum_launch(const float* src, int B, int nparts, int C, float* dst, long long dst_stride, hipStream_t s,
                           int src_step) {
     hipLaunchKernelGGL(partsum_kernel, dim3((C + 31) / 32, B), dim3(256), 0, s, src, nparts, C, dst, dst_stride, src_step);

@@ -190,25 +190,67 @@ def _dft_tables(n):
 
 
 class ForkContext:
-    """Second stream + fork / join events of ``ddimx_unet_fwd_forked`` for ONE owner: either a model's eager calls or one
-    graph capture.  An event set is never shared between eager launches and a capture, nor between two captures (a HIP event
-    last recorded inside a capture must not be re-recorded eagerly), and it must outlive every graph whose capture recorded
-    it and die after that graph: so whoever captures owns its context and drops it after the graph (``DDIMStepper.close``).
-    The events are created here -- eagerly, by a first record on the current stream; torch creates the hipEvent lazily and
-    that must not happen inside a capture."""
+    """Second stream + fork / join events of ``ddimx_unet_fwd_forked`` / ``ddimx_unet_bwd_forked`` for ONE owner: either a
+    model's eager calls or one graph capture.  An event set is never shared between eager launches and a capture, nor between
+    two captures (a HIP event last recorded inside a capture must not be re-recorded eagerly), and it must outlive every graph
+    whose capture recorded it and die after that graph: so whoever captures owns its context and drops it after the graph
+    (``DDIMStepper.close``).  The same holds for the STREAM: a capture's context (``private=True``) gets a HIP stream of its own,
+    created through the runtime and never handed to torch's stream pool -- a stream that has been forked into a capture is not
+    launched on eagerly afterwards (round 4: eager launches on such a stream, shared with the model's eager context, ended in
+    aborts inside a runtime thread).  The events are created here -- eagerly, by a first record on the current stream; torch
+    creates the hipEvent lazily and that must not happen inside a capture."""
 
-    def __init__(self, device, n_events, aux=None):
+    def __init__(self, device, n_events, private=False):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("a ForkContext must be created before the capture that uses it")
         self.device = device
-        self.aux = aux if aux is not None else torch.cuda.Stream(device=device)
-        self.events = [torch.cuda.Event() for _ in range(n_events)]
-        for e in self.events:
-            e.record()
+        self._owned = None
+        with torch.cuda.device(device):
+            if private:
+                self.aux = None
+                self._owned = self.aux_handle = _hip_stream_create()
+            else:
+                self.aux = torch.cuda.Stream(device=device)
+                self.aux_handle = self.aux.cuda_stream
+            self.events = [torch.cuda.Event() for _ in range(n_events)]
+            for e in self.events:
+                e.record()
 
     def event_array(self):
         import ctypes
         return (ctypes.c_void_p * len(self.events))(*[e.cuda_event for e in self.events])
+
+    def __del__(self):
+        h, self._owned = getattr(self, "_owned", None), None
+        if h:
+            try:
+                _hip_stream_destroy(h)
+            except Exception:
+                pass
+
+
+def _hip():
+    import ctypes
+    lib = getattr(_hip, "_lib", None)
+    if lib is None:
+        lib = _hip._lib = ctypes.CDLL("libamdhip64.so")  # already mapped by torch / libddimx.so
+        lib.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        lib.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    return lib
+
+
+def _hip_stream_create():
+    import ctypes
+    h = ctypes.c_void_p()
+    err = _hip().hipStreamCreateWithFlags(ctypes.byref(h), 1)  # hipStreamNonBlocking
+    if err != 0 or not h.value:
+        raise RuntimeError("hipStreamCreateWithFlags failed: %d" % err)
+    return h.value
+
+
+def _hip_stream_destroy(h):
+    import ctypes
+    _hip().hipStreamDestroy(ctypes.c_void_p(h))
 
 
 class _UNetTrainFn(torch.autograd.Function):
@@ -278,7 +320,7 @@ class _UNetTrainFn(torch.autograd.Function):
             fc = None
             if model.bwd_fork:
                 fc = model._capture_bwd_ctx if torch.cuda.is_current_stream_capturing() else model._eager_bwd_context(x.device)
-            side = (ctypes.c_void_p(fc.aux.cuda_stream), fc.event_array(), len(fc.events)) if fc is not None else (None, None, 0)
+            side = (ctypes.c_void_p(fc.aux_handle), fc.event_array(), len(fc.events)) if fc is not None else (None, None, 0)
             if staged is not None and sync.active():
                 # data parallel with overlap: the backward records an event per gradient bucket (up path, bottleneck, the rest)
                 # and each bucket's all-reduce is issued on a side stream as soon as its event has fired, while the remaining
@@ -510,15 +552,15 @@ class Model(_Node):
         return [r for r in refs if r is not None]
 
     def new_fork_context(self, device):
-        """A ForkContext for ONE graph capture (owned by the capturer); shares the model's aux stream."""
+        """A ForkContext for ONE graph capture (owned by the capturer), with a stream of its own."""
         ef = self._eager_context(device)
-        return ForkContext(device, len(ef.events), aux=ef.aux)
+        return ForkContext(device, len(ef.events), private=True)
 
     def new_bwd_fork_context(self, device):
         """A ForkContext for the backward inside ONE graph capture (``train.GraphedTrainStep`` owns it and sets
-        ``_capture_bwd_ctx`` around its capture); shares the model's weight-gradient stream."""
+        ``_capture_bwd_ctx`` around its capture), with a stream of its own."""
         ef = self._eager_bwd_context(device)
-        return ForkContext(device, len(ef.events), aux=ef.aux)
+        return ForkContext(device, len(ef.events), private=True)
 
     def _eager_bwd_context(self, device):
         ef = self._eager_bwd_fork
@@ -641,7 +683,7 @@ class Model(_Node):
                 # the current stream before the call returns
                 _lib.check(lib.ddimx_unet_fwd_forked(self._handle, _lib.ptr(self._packed), ctypes.byref(tables), _lib.ptr(wsp),
                                                      wsp.numel(), _lib.ptr(x), _lib.ptr(tt), _lib.ptr(out), b, t_len, _lib.stream(),
-                                                     ctypes.c_void_p(fc.aux.cuda_stream), fc.event_array(), len(fc.events), mask))
+                                                     ctypes.c_void_p(fc.aux_handle), fc.event_array(), len(fc.events), mask))
             else:
                 _lib.check(lib.ddimx_unet_fwd(self._handle, _lib.ptr(self._packed), ctypes.byref(tables),
                                               _lib.ptr(wsp), wsp.numel(), _lib.ptr(x), _lib.ptr(tt),

@@ -109,18 +109,25 @@ class DDIMStepper:
         if g is not None:
             torch.cuda.synchronize(self.xt.device)  # no replay in flight when the executable graph goes away
             del g
+            torch.cuda.synchronize(self.xt.device)  # ... and the runtime has finished with it before its events / buffers go
         self._ctx = self._refs = None
 
     def close(self):
         self._drop_graph()
 
     def __del__(self):
+        # a stepper that is simply dropped may still have its last replay in flight: the same order as close(), with the same
+        # synchronisation (an executable graph destroyed under a running replay, then the events and buffers it references
+        # freed, is a use-after-free inside the runtime's completion thread)
         try:
-            g, self.graph = self.graph, None
-            del g                     # hipGraphExecDestroy first ...
-            self._ctx = self._refs = None  # ... then the events its capture recorded and the buffers it points at
+            self._drop_graph()
         except Exception:
-            pass
+            try:
+                g, self.graph = self.graph, None
+                del g                     # hipGraphExecDestroy first ...
+                self._ctx = self._refs = None  # ... then the events its capture recorded and the buffers it points at
+            except Exception:
+                pass
 
     def _capture(self):
         dev = self.xt.device

@@ -77,11 +77,16 @@ def train_step(model, x, state, alphas, e=None, t=None, _assign_grads=False):
         # (GraphedTrainStep) the same gradients, taken with respect to the fresh leaf aliases the forward differentiated
         # (model._alias_leaves) and assigned to the parameters: no AccumulateGrad node of an earlier step is involved
         params = [p for _, p in model.named_parameters()]
-        for p, g in zip(params, torch.autograd.grad(loss, model._leaf_aliases, allow_unused=True)):
+        with torch.autograd.set_multithreading_enabled(False):  # (the capture stays in the capturing thread)
+            grads = torch.autograd.grad(loss, model._leaf_aliases, allow_unused=True)
+        for p, g in zip(params, grads):
             p.grad = g
         model._leaf_aliases = None
     else:
-        loss.backward()
+        # the backward is ONE autograd node (model._UNetTrainFn) that launches on two streams and records events: it runs in the
+        # calling thread, not in the engine's device thread (nothing to parallelise, and no cross-thread stream state)
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward()
     norms = {}
     for name, g in state.grad_group.items():
         if g.config.grad_clip is not None:
@@ -205,7 +210,13 @@ class GraphedTrainStep:
             self.model._ensure_tables(x.size(2), dev)
         # the captured backward forks its weight gradients onto a second stream (ddimx_unet_bwd_forked): this capture's own event set
         self._bwd_ctx = None
-        if getattr(self.model, "bwd_fork", False) and hasattr(self.model, "new_bwd_fork_context"):
+        # -- only on request (DDIMX_CAPTURE_FORK=1): measured on this ROCm, a process that DESTROYS a captured training graph with the
+        # second-stream branch in it and then goes on launching eagerly on two streams is killed by an abort / segfault inside a runtime
+        # thread in 5 of 12 runs of tests/test_gpu_configs.py, against 0 of 8 with the captured backward on one stream
+        # (tools/dbg/bisect_graphed.sh); the eager step keeps its branch, the replayed step gives up 1.2 ms of 49
+        import os
+        if (getattr(self.model, "bwd_fork", False) and hasattr(self.model, "new_bwd_fork_context")
+                and os.environ.get("DDIMX_CAPTURE_FORK", "0") == "1"):
             self._bwd_ctx = self.model.new_bwd_fork_context(dev)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -249,17 +260,22 @@ class GraphedTrainStep:
         if g is not None:
             torch.cuda.synchronize()
             del g
+            torch.cuda.synchronize()  # the runtime has finished with the graph before its events / buffers go
         self._refs = None
         self._bwd_ctx = None
 
     def __del__(self):
+        # dropped without close(): the last replay may still be in flight -- same order, same synchronisation (sampler.DDIMStepper)
         try:
-            g, self.graph = self.graph, None
-            del g
-            self._refs = None
-            self._bwd_ctx = None
+            self.close()
         except Exception:
-            pass
+            try:
+                g, self.graph = self.graph, None
+                del g
+                self._refs = None
+                self._bwd_ctx = None
+            except Exception:
+                pass
 
     def __call__(self, x, e=None, t=None):
         n = x.size(0)

@@ -11,7 +11,7 @@ export PYTHONFAULTHANDLER=1
 export LIBC_FATAL_STDERR_=1   # glibc's heap-corruption messages go to stderr (the log), not to a controlling terminal
 # native backtrace of whichever thread aborts / segfaults (faulthandler shows Python frames only): tools/dbg/abort_bt.c
 R=$(cd "$(dirname "$0")/.." && pwd)
-[ -f $R/tools/dbg/abort_bt.so ] || gcc -shared -fPIC -O1 -o $R/tools/dbg/abort_bt.so $R/tools/dbg/abort_bt.c 2>/dev/null
+[ -f $R/tools/dbg/abort_bt.so ] || gcc -shared -fPIC -O1 -o $R/tools/dbg/abort_bt.so $R/tools/dbg/abort_bt.c -ldl 2>/dev/null
 [ -f $R/tools/dbg/abort_bt.so ] && export LD_PRELOAD=$R/tools/dbg/abort_bt.so
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q -p no:cacheprovider "$@" > "$log" 2>&1
 rc=$?
