@@ -746,7 +746,9 @@ static void wgrad_plan(const WgradGeom& g, int B, int Hd, int Wd, int* tiles_x, 
     *tiles_x = cdiv(Wd, g.tw);
     *tiles_y = cdiv(Hd, g.th);
     const int total = B * *tiles_x * *tiles_y;
-    int want = 512 / g.grid_y;
+    // workgroups per launch: 2 per CU alone on the chip; 1.5 per CU where the launch shares the chip with the data-gradient chain (the
+    // weight-gradient branch, WgSide: 49.1-49.4 vs 49.5-49.9 ms per step, profiles/r04/wgside/wgrad_split_ab.txt)
+    int want = (knobs().wgrad_side != 0 ? 384 : 512) / g.grid_y;
     if (const int v = knobs().wgrad_split; v > 0) want = v / g.grid_y;  // tuning hook
     if (want < 1) want = 1;
     if (want > total) want = total;

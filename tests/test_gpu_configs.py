@@ -521,11 +521,12 @@ def test_staged_backward_buckets_are_final_when_their_event_fires():
     losses.noise_estimation_loss(m, x0, t, e, alphas).backward()
     torch.cuda.synchronize()
     flat = m._flat_grad
-    assert torch.equal(flat, plain), "the staged backward must compute the same gradients"
+    # (bitwise: unowned words of the buffer -- alignment padding -- may hold NaN patterns left by other tests' poison)
+    assert torch.equal(flat.view(torch.int32), plain.view(torch.int32)), "the staged backward must compute the same gradients"
     (a0, b0), (a1, b1), (a2, b2) = seen["ranges"]
     assert a2 == 0 and b2 == a0 and b0 == a1 and b1 == flat.numel()
     for snap, (lo, hi) in zip(seen["snaps"], seen["ranges"]):
-        assert torch.equal(snap, flat[lo:hi]), "a bucket changed after its event fired"
+        assert torch.equal(snap.view(torch.int32), flat[lo:hi].view(torch.int32)), "a bucket changed after its event fired"
     total, layout = m._grad_layout(__import__("ddim_audio_amd")._lib.load())
     for (name, _), (off, numel, _) in zip(m.named_parameters(), layout):
         b = 0 if name.startswith("up_modules.") else (1 if name.startswith("transformer.") else 2)

@@ -58,13 +58,15 @@ def test_staged_grad_sync_runs_on_rccl():
         for _ in range(2):
             losses.noise_estimation_loss(m, x0, t, e, alphas).backward()
             torch.cuda.synchronize()
-            assert torch.equal(m._flat_grad, plain)
+            # bitwise: the words no parameter owns (64-float alignment padding, the temb.te slot) are torch.empty garbage that the
+            # backward never writes -- after the NaN-poisoning tests of this suite they may hold NaN patterns, which == calls unequal
+            assert torch.equal(m._flat_grad.view(torch.int32), plain.view(torch.int32)), "the staged backward must compute the same gradients"
             m.zero_grad(set_to_none=True)
         # the un-overlapped form of the same collective
         flat = plain.clone()
         ddist.make_grad_sync(bucket_mb=16, overlap=False)(flat)
         torch.cuda.synchronize()
-        assert torch.equal(flat, plain)
+        assert torch.equal(flat.view(torch.int32), plain.view(torch.int32))
     finally:
         m.grad_sync = None
         if own:
