@@ -32,15 +32,19 @@ def main():
     alphas = alphas.cuda()
     x = torch.randn(b, 2, t_len, 256, device="cuda")
     torch.manual_seed(1234)
-    for _ in range(2):
-        loss, _ = train.train_step(m, x, state, alphas)
-    torch.cuda.synchronize()
-    phases = {}
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss, norms = train.train_step(m, x, state, alphas)
-    torch.cuda.synchronize()
-    dtm = (time.perf_counter() - t0) / steps
+    import contextlib, os
+    # A/B: DDIMX_MAIN_PRIORITY=-1 runs the step on a high-priority stream (the weight-gradient branch keeps a normal one)
+    main = torch.cuda.Stream(priority=int(os.environ["DDIMX_MAIN_PRIORITY"])) if "DDIMX_MAIN_PRIORITY" in os.environ else None
+    with (torch.cuda.stream(main) if main is not None else contextlib.nullcontext()):
+        for _ in range(2):
+            loss, _ = train.train_step(m, x, state, alphas)
+        torch.cuda.synchronize()
+        phases = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, norms = train.train_step(m, x, state, alphas)
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / steps
     # forward-only and forward+backward split
     m.train()
     e = torch.randn_like(x)
