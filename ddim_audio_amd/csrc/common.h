@@ -32,6 +32,24 @@ __device__ __forceinline__ float gelu_new_f(float v) {
 }
 
 // ---- 16-byte piece <-> floats ------------------------------------------------------------------
+// 16-byte non-temporal load / store (`global_load/store_dwordx4 ... nt`): for tensors that are streamed once and are larger than the
+// 256 MiB Infinity Cache, so that they do not push lines that WILL be re-read out of it (the element-wise passes of a training step
+// at 32 samples: -5 % per pass, profiles/r04/nt/)
+typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+    const nt_u32x4 v = __builtin_nontemporal_load((const nt_u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store16(void* p, const uint4 v) {
+    nt_u32x4 w;
+    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, (nt_u32x4*)p);
+}
+// host side: does one tensor of an element-wise pass exceed the Infinity Cache?  (DDIMX_NT=0 turns the non-temporal paths off: A/B)
+static inline int nt_streaming(size_t tensor_bytes) {
+    static const int on = getenv("DDIMX_NT") ? atoi(getenv("DDIMX_NT")) : 1;
+    return on && tensor_bytes > ((size_t)256 << 20) ? 1 : 0;
+}
 template <typename T> struct Piece;  // a 16-byte run of elements
 template <> struct Piece<float> {
     static constexpr int N = 4;

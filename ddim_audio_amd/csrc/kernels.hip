@@ -584,7 +584,8 @@ int resid_nparts(int dtype, int HW, int C) {
 template <typename T, bool HF32, bool HSILU = false>
 __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __restrict__ hv,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    T* y, float* __restrict__ stats, int HW, int C, const GnIn gn, int groups, int iters) {
+                                                    T* y, float* __restrict__ stats, int HW, int C, const GnIn gn, int groups, int iters,
+                                                    int nt) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [R][C*2]
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -600,12 +601,12 @@ __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __re
     constexpr int HN = HF32 ? EPB / 4 : 1;
     const size_t sbase = (size_t)b * HW * C;
     auto load = [&](size_t e, uint4& vx, uint4 (&vh)[HN]) __attribute__((always_inline)) {
-        vx = *(const uint4*)(x + e);
+        vx = nt ? nt_load16(x + e) : *(const uint4*)(x + e);  // (nt: uniform)
         if constexpr (HF32) {
 #pragma unroll
             for (int k = 0; k < HN; ++k) vh[k] = *(const uint4*)((const float*)hv + e + 4 * k);
         } else {
-            vh[0] = *(const uint4*)((const T*)hv + e);
+            vh[0] = nt ? nt_load16((const T*)hv + e) : *(const uint4*)((const T*)hv + e);
         }
     };
     auto process = [&](size_t e, const uint4& vx, const uint4 (&vh)[HN]) __attribute__((always_inline)) {
@@ -623,7 +624,8 @@ __global__ void __launch_bounds__(256) resid_kernel(const T* x, const void* __re
 #pragma unroll
         for (int j = 0; j < EPB; ++j) fx[j] = fx[j] + fmaf(HSILU ? silu_f(fh[j]) : fh[j], sc[j], sh[j]);
         const uint4 pv = Piece<T>::pack(fx);
-        *(uint4*)(y + e) = pv;
+        if (nt) nt_store16(y + e, pv);
+        else *(uint4*)(y + e) = pv;
         Piece<T>::unpack(pv, fx);
 #pragma unroll
         for (int j = 0; j < EPB; ++j) { s[j] += fx[j]; q[j] = fmaf(fx[j], fx[j], q[j]); }
@@ -701,12 +703,13 @@ hipError_t resid_launch(int dtype, const void* x, const void* h, int h_f32, cons
     const size_t lds = (size_t)(bd / cpp) * C * 2 * 4 + (size_t)C * 2 * 4 + 4 * kGroups * 2 * 4;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
 #define DDIMX_RESID(TT, HF)                                                                                     \
-    hipLaunchKernelGGL((resid_kernel<TT, HF>), grid, dim3(bd), lds, s, (const TT*)x, h, scale, shift, (TT*)y, stats, HW, C, g, groups, iters)
+    hipLaunchKernelGGL((resid_kernel<TT, HF>), grid, dim3(bd), lds, s, (const TT*)x, h, scale, shift, (TT*)y, stats, HW, C, g, groups, iters, nt)
+    const int nt = nt_streaming((size_t)B * HW * C * (dtype == DT_BF16 ? 2 : 4));
     if (h_f32 == 2) {  // training forward: h holds the pre-activation, y = x + SiLU(h)*scale + shift
         if (dtype == DT_BF16)
-            hipLaunchKernelGGL((resid_kernel<__bf16, false, true>), grid, dim3(bd), lds, s, (const __bf16*)x, h, scale, shift, (__bf16*)y, stats, HW, C, g, groups, iters);
+            hipLaunchKernelGGL((resid_kernel<__bf16, false, true>), grid, dim3(bd), lds, s, (const __bf16*)x, h, scale, shift, (__bf16*)y, stats, HW, C, g, groups, iters, nt);
         else
-            hipLaunchKernelGGL((resid_kernel<float, false, true>), grid, dim3(bd), lds, s, (const float*)x, h, scale, shift, (float*)y, stats, HW, C, g, groups, iters);
+            hipLaunchKernelGGL((resid_kernel<float, false, true>), grid, dim3(bd), lds, s, (const float*)x, h, scale, shift, (float*)y, stats, HW, C, g, groups, iters, nt);
     } else if (dtype == DT_BF16) { if (h_f32) DDIMX_RESID(__bf16, true); else DDIMX_RESID(__bf16, false); }
     else { if (h_f32) DDIMX_RESID(float, true); else DDIMX_RESID(float, false); }
 #undef DDIMX_RESID

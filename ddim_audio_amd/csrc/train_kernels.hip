@@ -114,7 +114,7 @@ static inline int tr_nparts(int dtype, int HW, int C) { return resid_nparts(dtyp
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__ g, const T* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           float* __restrict__ stats, int HW, int C, int iters) {
+                                                           float* __restrict__ stats, int HW, int C, int iters, int nt) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
             const long long pc = pc0 + (long long)(it0 + k) * bd;
             ok[k] = it0 + k < iters && pc < pieces;
             const size_t e = sbase + (size_t)(ok[k] ? pc : 0) * EPB;
-            vg[k] = *(const uint4*)(g + e);
-            vu[k] = *(const uint4*)(u + e);
+            vg[k] = nt ? nt_load16(g + e) : *(const uint4*)(g + e);
+            vu[k] = nt ? nt_load16(u + e) : *(const uint4*)(u + e);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -179,7 +179,7 @@ hipError_t gn_bwd_stats_launch(int dtype, int mode, const void* g, const void* u
     if (bd % cpp) return hipErrorInvalidValue;
     dim3 grid(tr_nparts(dtype, HW, C), B);
     const size_t lds = (size_t)(bd / cpp) * C * 2 * 4;
-#define DDIMX_L(TT, M) hipLaunchKernelGGL((gn_bwd_stats_kernel<TT, M>), grid, dim3(bd), lds, s, (const TT*)g, (const TT*)u, scale, shift, stats, HW, C, resid_iters(dtype, HW, C))
+#define DDIMX_L(TT, M) hipLaunchKernelGGL((gn_bwd_stats_kernel<TT, M>), grid, dim3(bd), lds, s, (const TT*)g, (const TT*)u, scale, shift, stats, HW, C, resid_iters(dtype, HW, C), nt_streaming((size_t)B * HW * C * (dtype == DT_BF16 ? 2 : 4)))
     if (dtype == DT_BF16) { if (mode) DDIMX_L(__bf16, 1); else DDIMX_L(__bf16, 0); }
     else { if (mode) DDIMX_L(float, 1); else DDIMX_L(float, 0); }
 #undef DDIMX_L
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ coef, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ out,
                                                            float* __restrict__ sums, int HW, int C, int iters,
-                                                           const T* __restrict__ nu, float* __restrict__ nstats) {
+                                                           const T* __restrict__ nu, float* __restrict__ nstats, int nt) {
     constexpr int EPB = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -435,12 +435,17 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
             const long long pc = pc0 + (long long)(it0 + k) * bd;
             ok[k] = it0 + k < iters && pc < pieces;
             e[k] = sbase + (size_t)(ok[k] ? pc : 0) * EPB;
-            vg[k] = *(const uint4*)(g + e[k]);
-            vu[k] = *(const uint4*)(u + e[k]);
+            if (nt) {  // (uniform) streamed once: keep the lines out of the caches' replacement order
+                vg[k] = nt_load16(g + e[k]);
+                vu[k] = nt_load16(u + e[k]);
+            } else {
+                vg[k] = *(const uint4*)(g + e[k]);
+                vu[k] = *(const uint4*)(u + e[k]);
+            }
             if (MODE == 1) {
-                vy[k] = *(const uint4*)(gy + e[k]);
-                ve[k] = *(const uint4*)(pex + e[k]);
-                if (chain) vn[k] = *(const uint4*)(nu + e[k]);
+                vy[k] = nt ? nt_load16(gy + e[k]) : *(const uint4*)(gy + e[k]);
+                ve[k] = nt ? nt_load16(pex + e[k]) : *(const uint4*)(pex + e[k]);
+                if (chain) vn[k] = nt ? nt_load16(nu + e[k]) : *(const uint4*)(nu + e[k]);
             }
         }
 #pragma unroll
@@ -468,7 +473,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                 }
             }
             const uint4 pv = Piece<T>::pack(fo);
-            *(uint4*)(out + e[k]) = pv;
+            if (nt) nt_store16(out + e[k], pv);
+            else *(uint4*)(out + e[k]) = pv;
             if (MODE == 1 && chain) {
                 float fn[EPB];
                 Piece<T>::unpack(pv, fo);  // the values as stored: what the separate pass would read
@@ -521,10 +527,11 @@ hipError_t gn_bwd_apply_launch(int dtype, int mode, const void* g, const void* u
     if (bd % cpp) return hipErrorInvalidValue;
     dim3 grid(tr_nparts(dtype, HW, C), B);
     if (nstats && (mode != 1 || !nu)) return hipErrorInvalidValue;
+    const int nt = nt_streaming((size_t)B * HW * C * (dtype == DT_BF16 ? 2 : 4));
     const size_t lds = (size_t)(bd / cpp) * C * 4 * (nstats ? 2 : 1);
 #define DDIMX_L(TT, M)                                                                                                      \
     hipLaunchKernelGGL((gn_bwd_apply_kernel<TT, M>), grid, dim3(bd), lds, s, (const TT*)g, (const TT*)u, (const TT*)gy, \
-                       (const TT*)extra, coef, scale, shift, (TT*)out, sums, HW, C, resid_iters(dtype, HW, C), (const TT*)nu, nstats)
+                       (const TT*)extra, coef, scale, shift, (TT*)out, sums, HW, C, resid_iters(dtype, HW, C), (const TT*)nu, nstats, nt)
     if (dtype == DT_BF16) { if (mode) DDIMX_L(__bf16, 1); else DDIMX_L(__bf16, 0); }
     else { if (mode) DDIMX_L(float, 1); else DDIMX_L(float, 0); }
 #undef DDIMX_L
