@@ -75,7 +75,11 @@ class DDIMStepper:
         xt, t, x0 = self.xt, self.t, self.x0
         _lib.check(lib.ddimx_step_begin(_lib.ptr(self.coef), _lib.ptr(self.counter), _lib.ptr(t), t.numel(), st))
         if self.native:
-            et = self.model(xt, t, _slot=self.slot, _fork=self.fork, _ctx=self._ctx, _out=self.eps)
+            # a graph stepper's EAGER launches (the sizing step in front of a capture, the fallback after its graph went stale) stay on
+            # one stream: the two-shard fork is for the captured step (and for eager-only steppers) -- same bits either way, and no eager
+            # two-stream launch right after an executable graph with parallel branches was destroyed
+            fork = self.fork and (not self.use_graph or torch.cuda.is_current_stream_capturing())
+            et = self.model(xt, t, _slot=self.slot, _fork=fork, _ctx=self._ctx, _out=self.eps)
         else:
             et = self.model(xt, t)
             if et.dtype != torch.float32 or not et.is_contiguous():
