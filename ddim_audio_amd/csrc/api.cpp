@@ -22,7 +22,7 @@ namespace ddimx {
 // Tuning hooks (A/B runs of tools/*.py only): the DDIMX_* environment variables are read ONCE per process, at the first
 // library call that needs one, never per launch.
 struct Knobs {
-    int fnet_dense, conv_pipe, pipe_tpw, bwd_stats_fused, gn_dbg, conv_wreg, conv_wps, conv_var, wgrad_split, wgrad_side, wgrad_hold, wgrad_flush;
+    int fnet_dense, conv_pipe, pipe_tpw, bwd_stats_fused, gn_dbg, conv_wreg, conv_wps, conv_var, wgrad_split, wgrad_side, wgrad_hold;
     Knobs() {
         auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         conv_var = geti("DDIMX_CONV_VAR", -1);     // tools/conv_tune.py: force a candidate tile variant of conv_mfma_kernel
@@ -32,7 +32,6 @@ struct Knobs {
         // ... and the up path's weight gradients of levels < wgrad_hold wait (in `du` buffers of their own) for the bottleneck's
         // backward, whose launch-bound FNet kernels leave the chip idle (WgSide::held)
         wgrad_hold = geti("DDIMX_WGRAD_HOLD", 2);
-        wgrad_flush = geti("DDIMX_WGRAD_FLUSH", 99);  // A/B: issue the held ones when the up path's backward enters this level (default: at the FNet)
         // A/B, GroupNorm-backward statistics -- bit 0: of GN1 / GN0 in the data-gradient convs' epilogue, bit 1: of GN2 in the previous
         // block's last apply pass; 0 = every statistics pass on its own
         bwd_stats_fused = geti("DDIMX_BWD_STATS_FUSED", 3);
@@ -2010,7 +2009,6 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
     bool have_stats = false;  // w.stats holds the first statistics pass of the block about to run
     for (int l = 0; l < L; ++l) {
         const int H = T >> l, W = f.f_size >> l, C = f.ch[l];
-        if (sd.on() && l == knobs().wgrad_flush) CHK(sd.flush_held(s));
         for (int r = f.res[l] - 1; r >= 0; --r) {
             const void* xin = r ? tp.up_y[l][r - 1] : tp.up_in[l];
             void* dx = r == 0 ? w.GS[l] : (gy == w.Gb[l] ? w.Ga[l] : w.Gb[l]);
