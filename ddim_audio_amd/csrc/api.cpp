@@ -796,6 +796,7 @@ struct WgSide {
     void* const* ev = nullptr;
     int n = 0, used = 0;
     int early = 0;             // DDIMX_WGRAD_SIDE=2 (A/B): fork each weight gradient as soon as its `du` exists
+    bool early_block = false;  // ... for the block about to run only (the walk's last block: nothing follows that its branch could run beside)
     float* partial = nullptr;
     void* du[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t du_free[2] = {nullptr, nullptr};
@@ -894,7 +895,7 @@ static int run_resblock_bwd(int dtype, int C, const void* x, const RBTape& tp, c
     void* const du1 = hold ? hold[1] : (side ? sd->du[2 * par + 1] : w.du);
     hipStream_t const sw = side ? sd->st : s;              // the weight gradients' stream
     float* const wpart = side ? sd->partial : w.partial;
-    const bool early = side && sd->early && !hold;
+    const bool early = side && (sd->early || sd->early_block) && !hold;
     const void* const u1 = tp.u1;
     const float *const sc1 = tp.sc(1, B, C), *const sh1 = tp.sh(1, B, C), *const sc0 = tp.sc(0, B, C), *const sh0 = tp.sh(0, B, C);
     float *const gw1 = gr.w1, *const gw0 = gr.w0;
@@ -2066,6 +2067,9 @@ int ddimx_unet_bwd_forked(ddimx_handle h, const void* packed, const void* packed
             const RBW& rbw = c->down_rb[l][r];
             CHK(next_slots());
             const void* nu2 = chain_stats && r > 0 ? tp.dn_rb[l][r - 1].u2 : nullptr;
+            // the walk's last block forks its weight gradients as soon as their `du` exists: nothing follows that they could run beside,
+            // so they start under the block's own data-gradient convs (48.05 vs 48.20 ms per step, profiles/r04/wgside/last_block_early_ab.txt)
+            sd.early_block = l == 0 && r == 0;
             CHK(run_resblock_bwd(dt, C, xin, tp.dn_rb[l][r], gy, (l == 0 && r == 0) ? w.gA : nullptr, dx, pf(c, packed, rbw.g0),
                                  pf(c, packed, rbw.g1), pf(c, packed, rbw.g2), pb + bp.dn_wd0[l][r], pb + bp.dn_wd1[l][r],
                                  rb_grads(rbw, w.dtemb + c->emb_off_down[down_bi(f, l, r)]), rw, B, H, W, s, &sd, have_stats, nu2));
