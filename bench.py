@@ -232,7 +232,7 @@ def sampler_leg(cfg_strs, B, T, steps, seed=4321):
         return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
-def training_leg(args, cfg, dev, rank, world, backend, steps=3):
+def training_leg(args, cfg, dev, rank, world, backend, steps=10):
     """Secondary measurement (never the headline `value`): BASELINE config 4's training step -- noise + antithetic t,
     loss, backward of the whole network, clip, fused AdamW (both groups), EMA -- at `--train-batch` samples per GPU, data
     parallel over the ranks (one all-reduce of the flat gradient buffer per step).  Failures are reported, not raised."""
@@ -250,7 +250,7 @@ def training_leg(args, cfg, dev, rank, world, backend, steps=3):
         alphas = schedule.make_schedule(tcfg.diffusion)[1].to(dev)
         b = args.train_batch
         x = torch.randn(b, 2, args.t_size, tcfg.model.f_size, device=dev)
-        for _ in range(2):
+        for _ in range(3):
             train.train_step(m, x, state, alphas)
         torch.cuda.synchronize()
         if world > 1:
